@@ -1,0 +1,178 @@
+/*
+ * tiler_slider.h — C-ABI of the MI355X-native batched Tiler-Slider environment.
+ *
+ * The reference (AnimeshSinha1309/tiler-slider) has no FFI boundary: its hot
+ * path is a set of Python methods on one board.  This header is the boundary a
+ * maintainer would bind (ctypes) to run N independent
+ * boards per call on one MI355X.  Each entry point names the reference
+ * method(s) it replaces as `ref: file:line` (paths relative to the reference
+ * repository root).
+ *
+ * Conventions
+ *  - Every pointer in ts_state / ts_step_out is a DEVICE pointer owned by the
+ *    caller (PyTorch-ROCm tensors in the shipped host code).  The library never
+ *    allocates, frees or retains them.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every
+ *    call is asynchronous on that stream; none synchronises the device.
+ *  - Return value: TS_OK (0) or a negative ts_status.  No C++ exception crosses
+ *    this boundary.  The library keeps no global mutable state; calls are
+ *    re-entrant.
+ *
+ * Device data layout (struct-of-arrays, board index fastest; N = n_boards,
+ * S = size, C = S*S, cell id p = r*S + c with row 0 at the top):
+ *    pos, init  uint8  [n_tiles  ][N]   cell id of tile t of board n
+ *    tgt        uint8  [n_targets][N]   cell id of target j of board n
+ *    blk        uint32 [W][N]           W = ts_blk_words(S); bit (p & 31) of word
+ *                                       (p >> 5) set <=> cell p is an obstacle
+ *    step_count int32  [N]
+ *    done       uint8  [N]              0 / 1 (latched until reset)
+ *    actions    uint8  [N]              0 UP, 1 DOWN, 2 LEFT, 3 RIGHT
+ *    flags      uint8  [N]              TS_FLAG_* bits of the step just taken
+ *    obs        float32[N][S][S][3]     == np.stack of the reference observation
+ *    onehot     float32[N][Ch][S][S]    Ch = ts_onehot_channels(dims)
+ *    reward     int32  [N]
+ *    valid      uint8  [N]              bit d set <=> move d changes the board
+ */
+#ifndef TILER_SLIDER_H
+#define TILER_SLIDER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS_ABI_VERSION 1
+#define TS_MAX_SIZE 16   /* cell ids are uint8: C = S*S <= 256 */
+#define TS_MAX_TILES 255 /* observation stores tile index + 1 in one byte */
+
+/* ref: explainrl/environment/state.py:29-35 (GameState.Move values) */
+#define TS_MOVE_UP 0
+#define TS_MOVE_DOWN 1
+#define TS_MOVE_LEFT 2
+#define TS_MOVE_RIGHT 3
+
+typedef enum ts_status {
+  TS_OK = 0,
+  TS_ERR_NULL = -1,  /* a required pointer is NULL */
+  TS_ERR_DIMS = -2,  /* inconsistent dims (negative counts, more pieces than cells, ...) */
+  TS_ERR_LIMIT = -3, /* size / tile count above TS_MAX_* */
+  TS_ERR_HIP = -4,   /* the HIP runtime refused the launch (see ts_last_hip_error) */
+  TS_ERR_ARG = -5    /* invalid mode bits or argument combination */
+} ts_status;
+
+/* Per-board flag byte written by ts_step.
+ * ref: explainrl/environment/environment.py:126-141 (the info dict of step()) */
+#define TS_FLAG_IS_WON 0x01u       /* info['is_won'] */
+#define TS_FLAG_INVALID_MOVE 0x02u /* info['invalid_move']: no tile changed cell */
+#define TS_FLAG_SUCCESS 0x04u      /* info['success'] (key present iff set) */
+#define TS_FLAG_TIMEOUT 0x08u      /* info['timeout'] (key present iff set) */
+#define TS_FLAG_STEPPED_DONE 0x10u /* board was done on entry: the reference raises
+                                      RuntimeError (environment.py:113-114); here the
+                                      board is left untouched and this bit is set */
+#define TS_FLAG_AUTORESET 0x20u    /* TS_MODE_AUTORESET: board was done on entry and was
+                                      reset instead of stepped */
+#define TS_FLAG_BAD_ACTION 0x40u   /* action byte > 3: the reference raises ValueError/TypeError
+                                      (state.py:43-45, environment.py:116-117); board untouched */
+
+/* ts_step mode bits */
+#define TS_MODE_STRICT 0x0u    /* reference semantics; done boards are flagged, not stepped */
+#define TS_MODE_AUTORESET 0x1u /* done boards reset in place (vector-env convenience) */
+
+typedef struct ts_dims {
+  int64_t n_boards;    /* N >= 0 */
+  int32_t size;        /* S, 1..TS_MAX_SIZE          (GameState.size) */
+  int32_t n_tiles;     /* T, 0..TS_MAX_TILES         (len(current_locations)) */
+  int32_t n_targets;   /* Tt, 0..TS_MAX_TILES        (len(target_locations)) */
+  int32_t multi_color; /* 0 / 1                      (GameState.multi_color) */
+  int32_t max_steps;   /* >= 1                       (TilerSliderEnv.max_steps) */
+  int32_t reserved;    /* must be 0 */
+} ts_dims;
+
+typedef struct ts_state {
+  uint8_t *pos;        /* [T][N]  current_locations */
+  const uint8_t *init; /* [T][N]  initial_locations (level) */
+  const uint8_t *tgt;  /* [Tt][N] target_locations  (level) */
+  const uint32_t *blk; /* [W][N]  is_blocked bitmask (level) */
+  int32_t *step_count; /* [N] */
+  uint8_t *done;       /* [N] */
+} ts_state;
+
+typedef struct ts_step_out {
+  uint8_t *flags;  /* [N]           required */
+  float *obs;      /* [N][S][S][3]  optional (NULL = do not encode) */
+  int32_t *reward; /* [N]           optional, build-defined Manhattan reward */
+  float *onehot;   /* [N][Ch][S][S] optional, build-defined one-hot planes */
+  uint8_t *valid;  /* [N]           optional, legality mask of the post-move board */
+} ts_step_out;
+
+/* --- introspection ------------------------------------------------------- */
+int32_t ts_abi_version(void);
+void ts_limits(int32_t *max_size, int32_t *max_tiles);
+const char *ts_status_string(int32_t status);
+/* hipError_t of the last failed launch on the calling thread (0 if none). */
+int32_t ts_last_hip_error(void);
+/* W: uint32 words of the obstacle bitmask for an S x S board = ceil(S*S/32). */
+int32_t ts_blk_words(int32_t size);
+/* Ch of the one-hot encoding: 1 + T + Tt if multi_color else 3. */
+int32_t ts_onehot_channels(const ts_dims *dims);
+/* Checks dims against the limits; TS_OK or the error ts_step would return. */
+int32_t ts_check_dims(const ts_dims *dims);
+
+/* --- hot path -------------------------------------------------------------- */
+
+/* reset(): pos <- init, step_count <- 0, done <- 0, obs <- encode(init) (obs may be NULL).
+ * ref: explainrl/environment/environment.py:82-98 (TilerSliderEnv.reset),
+ *      explainrl/environment/state.py:47-73 (GameState.__init__).  The reference's
+ *      move_to table (state.py:75-118) is not materialised: slide destinations are
+ *      recomputed from the obstacle bitmask inside ts_step. */
+int32_t ts_reset(const ts_dims *dims, const ts_state *st, float *obs, void *stream);
+
+/* step(): slide-and-pack every tile of every board in its action's direction, then
+ * win / invalid-move / timeout flags, step counter, done latch and the observation.
+ * ref: explainrl/environment/environment.py:100-143 (TilerSliderEnv.step),
+ *      explainrl/environment/state.py:120-170 (GameState.move),
+ *      explainrl/environment/state.py:172-186 (GameState.is_won),
+ *      explainrl/environment/state.py:188-211 (GameState.get_state_array). */
+int32_t ts_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions, uint32_t mode,
+                const ts_step_out *out, void *stream);
+
+/* get_valid_moves(): bit d of mask[n] set <=> Move d changes board n.  Ignores `done`.
+ * ref: explainrl/environment/environment.py:149-171. */
+int32_t ts_valid_moves(const ts_dims *dims, const ts_state *st, uint8_t *mask, void *stream);
+
+/* get_state_array() of the current positions, for all boards.
+ * ref: explainrl/environment/state.py:188-211. */
+int32_t ts_encode(const ts_dims *dims, const ts_state *st, float *obs, void *stream);
+
+/* Build-defined extensions (absent from the reference, environment.py:5 says reward is
+ * "handled separately"; parity unpinned vs the reference, pinned by oracle/):
+ *   one-hot: plane 0 obstacles; multi_color: plane 1+i tile i, plane 1+T+j target j;
+ *            single colour: plane 1 any tile, plane 2 any target.
+ *   reward : multi_color: -sum_i |r_i-tr_i|+|c_i-tc_i| over i < min(T,Tt);
+ *            single colour: -sum_i min_j manhattan(tile_i, target_j) (0 if Tt == 0). */
+int32_t ts_encode_onehot(const ts_dims *dims, const ts_state *st, float *onehot, void *stream);
+int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void *stream);
+
+/* --- synthetic inputs (bench / tests) --------------------------------------- */
+
+/* Random level per board with the distribution of the reference's level factory:
+ * n_obstacles + T + Tt distinct uniformly random cells; the first n_obstacles become
+ * obstacles, the next T tiles, the next Tt targets.  Writes blk, init and tgt (cast
+ * away const); board n uses the counter-based stream (seed, board_offset + n), so
+ * shards of one global batch can be generated independently on each GPU.
+ * ref: explainrl/environment/environment.py:202-234 (create_simple_env) for the
+ *      distribution only — the reference's MT19937 stream is reproduced on the host
+ *      (tiler_slider_amd.factory), not here. */
+int32_t ts_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int64_t board_offset,
+                    int32_t n_obstacles, void *stream);
+
+/* actions[n] = uniform {0,1,2,3} from the counter-based stream (seed, step_index,
+ * board_offset + n). */
+int32_t ts_fill_actions(int64_t n_boards, uint64_t seed, int64_t board_offset, int64_t step_index,
+                        uint8_t *actions, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TILER_SLIDER_H */
