@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched Tiler-Slider step() on MI355X.
+
+    python bench.py --gpus 1 --steps 500 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one ts_step launch over every board of the rank's shard (slide, flags, counters,
+done latch, float32 observation).  Workload = BASELINE.json configs[1]: 1,048,576 concurrent
+4x4 boards per GPU (T=2 tiles, K=2 obstacles, multi_color), synthetic random levels and
+actions, inputs resident in HBM before the timed region, autoreset so every board stays live.
+Boards shard across ranks with no data-path collective (weak scaling); the RCCL all-gather
+that hands observations to a single learner is timed separately and reported under
+"allgather".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+LEVEL_SEED = 0x715311DE
+ACTION_SEED = 0xAC710005
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guide: 6.29 TB/s is the measured copy ceiling)
+
+CONFIGS = {
+    # name: (size, tiles, obstacles, boards per GPU, extras)
+    "cfg1": dict(size=4, tiles=2, obstacles=2, boards=1 << 20, onehot=False, reward=False),
+    "cfg2": dict(size=5, tiles=2, obstacles=3, boards=1 << 20, onehot=True, reward=True),
+    "cfg4": dict(size=15, tiles=32, obstacles=24, boards=1 << 18, onehot=False, reward=False),
+}
+
+
+def algorithmic_bytes_per_board_step(size, tiles, onehot, reward, multi_color=True):
+    """read pos+tgt+blk+step+done+act, write pos+step+done+flags+obs."""
+    C = size * size
+    blk = 2 if C <= 16 else 4 * ((C + 31) // 32)
+    read = tiles + tiles + blk + 4 + 1 + 1
+    write = tiles + 4 + 1 + 1 + 12 * C
+    if onehot:
+        write += 4 * C * ((1 + 2 * tiles) if multi_color else 3)
+    if reward:
+        write += 4
+    return read + write
+
+
+def cpu_baseline(cfg, budget_s=10.0):
+    """The CPU oracle (a C port of the reference algorithm, OpenMP over boards) on the SAME
+    synthetic boards and action stream, on this box's host cores.  Reported, never the target."""
+    import numpy as np  # noqa: F401
+    from oracle import binding as orc
+    n = min(cfg["boards"], 1 << 20)
+    blk, init, tgt = orc.generate(cfg["size"], cfg["tiles"], cfg["tiles"], cfg["obstacles"], n, seed=LEVEL_SEED)
+    env = orc.OracleBatch(cfg["size"], True, 2**30, blk, init, tgt)
+    env.reset()
+    acts = [orc.fill_actions(n, seed=ACTION_SEED, step_index=i) for i in range(8)]
+    kw = dict(mode=orc.MODE_AUTORESET, reward=cfg["reward"], onehot=cfg["onehot"])
+    t0 = time.perf_counter()
+    env.step(acts[0], **kw)
+    env.step(acts[1], **kw)
+    per_step = (time.perf_counter() - t0) / 2
+    steps = max(3, min(400, int(budget_s / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        env.step(acts[i & 7], **kw)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": int(orc.lib().tso_num_threads()),
+            "kind": "port",
+            "sample": f"{n} boards x {steps} steps of the same workload (oracle/ts_oracle.c, OpenMP), {dt:.1f} s",
+            "reference_python_recorded": {"value": 9.2e4, "unit": "env-steps/s", "cores": 1,
+                                          "note": "reference TilerSliderEnv.step loop, 4x4 T2 K2, timed in the "
+                                                  "build container (BASELINE.md §2); the reference cannot travel"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg1")
+    ap.add_argument("--boards", type=int, default=None, help="boards per GPU (default: the config's)")
+    ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    cfg = dict(CONFIGS[args.config])
+    if args.boards:
+        cfg["boards"] = args.boards
+    n = cfg["boards"]
+    env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
+                                   seed=LEVEL_SEED, multi_color=True, max_steps=2**30, board_offset=rank * n,
+                                   device=device, auto_reset=True, with_reward=cfg["reward"],
+                                   with_onehot=cfg["onehot"])
+    env.reset()
+    ring = []
+    L = _cabi.lib()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    for i in range(16):
+        a = torch.empty(n, dtype=torch.uint8, device=device)
+        _cabi.check(L.ts_fill_actions(n, ACTION_SEED, rank * n, i, a.data_ptr(), stream), "ts_fill_actions")
+        ring.append(a)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        env.step_async(ring[i & 15])
+    graph = None
+    if args.graph:
+        torch.cuda.synchronize(device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(args.steps):
+                env.step_async(ring[i & 15])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    if graph is not None:
+        graph.replay()
+    else:
+        for i in range(args.steps):
+            env.step_async(ring[i & 15])
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
+
+    tm = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    wall, dev_ms = float(tm[0]), float(tm[1])
+    total_boards = n * world
+    value = total_boards * args.steps / wall
+
+    gather = None
+    if world > 1 and not args.no_gather:
+        gather = time_gathers(env, ring, world, n, dist, torch, device, min(args.steps, 20))
+
+    if rank == 0:
+        bps = algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
+        kern_s = dev_ms / 1e3 / args.steps
+        achieved = bps * n / kern_s / 1e9
+        line = {
+            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {n:,} concurrent {cfg['size']}x{cfg['size']} boards per GPU, "
+                                   f"T={cfg['tiles']} tiles, K={cfg['obstacles']} obstacles, multi_color, "
+                                   f"random actions, autoreset"
+                                   + (", + one-hot + Manhattan reward" if cfg["onehot"] else ""),
+                       "boards_per_gpu": n, "total_boards": total_boards, "obs": "float32 [N,S,S,3]",
+                       "launch": "hipGraph" if graph is not None else "eager",
+                       "parallelism": f"boards sharded over {world} GPU(s), no data-path collective",
+                       "level_seed": hex(LEVEL_SEED), "action_seed": hex(ACTION_SEED)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_small" if cfg["size"] <= 8 else "k_large",
+                         "kernel_us": kern_s * 1e6, "algorithmic_bytes_per_board_step": bps,
+                         "algorithmic_bytes_per_launch": bps * n,
+                         "note": "working set < 256 MiB Infinity Cache at cfg1/cfg2: rate may exceed pure-HBM"},
+        }
+        if gather is not None:
+            line["allgather"] = gather
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def time_gathers(env, ring, world, n, dist, torch, device, steps):
+    """Step + hand-off to a single learner, two ways: (a) RCCL all-gather of the float32
+    observations (what north_star names); (b) all-gather of the compact state (cell ids) and
+    re-encoding on the learner side with ts_encode."""
+    from tiler_slider_amd.distributed import ObservationGatherer
+    g = ObservationGatherer(env, world)
+    out = {}
+    for name, fn in (("obs_f32", g.gather_observations), ("compact_state_then_encode", g.gather_compact_and_encode)):
+        fn()
+        dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            env.step_async(ring[i & 15])
+            fn()
+        torch.cuda.synchronize(device)
+        dist.barrier()
+        dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        out[name] = {"value": n * world * steps / float(dt[0]), "unit": "env-steps/s", "steps": steps,
+                     "bytes_per_rank_per_step": g.bytes_per_step[name]}
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,12 @@ int32_t ts_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions,
  * ref: explainrl/environment/environment.py:149-171. */
 int32_t ts_valid_moves(const ts_dims *dims, const ts_state *st, uint8_t *mask, void *stream);
 
+/* is_won(): won[n] = 1 if board n is solved as it stands, else 0.  multi_color: tile i on
+ * target i for every i (and T == Tt); otherwise the set of tile cells equals the set of
+ * target cells.
+ * ref: explainrl/environment/state.py:172-186. */
+int32_t ts_is_won(const ts_dims *dims, const ts_state *st, uint8_t *won, void *stream);
+
 /* get_state_array() of the current positions, for all boards.
  * ref: explainrl/environment/state.py:188-211. */
 int32_t ts_encode(const ts_dims *dims, const ts_state *st, float *obs, void *stream);

@@ -64,6 +64,7 @@ def lib():
         L.tso_step.argtypes = [DP, SP, P, C.c_uint32, C.POINTER(StepOut)]
         L.tso_valid_moves.argtypes = [DP, SP, P]
         L.tso_encode.argtypes = [DP, SP, P]
+        L.tso_won.argtypes = [DP, SP, P]
         L.tso_encode_onehot.argtypes = [DP, SP, P]
         L.tso_reward.argtypes = [DP, SP, P]
         L.tso_generate.argtypes = [DP, SP, C.c_uint64, C.c_int64, C.c_int32]
@@ -201,6 +202,11 @@ class OracleBatch:
         m = np.empty(self.n, np.uint8)
         self._check(lib().tso_valid_moves(C.byref(self.dims), C.byref(self._state()), _p(m)))
         return m
+
+    def won(self):
+        w = np.empty(self.n, np.uint8)
+        self._check(lib().tso_won(C.byref(self.dims), C.byref(self._state()), _p(w)))
+        return w
 
     def encode(self):
         obs = self._obs_buf()

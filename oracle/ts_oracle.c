@@ -373,6 +373,20 @@ int32_t tso_valid_moves(const ts_dims *d, const ts_state *st, uint8_t *mask) {
   return TS_OK;
 }
 
+int32_t tso_won(const ts_dims *d, const ts_state *st, uint8_t *won) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (!st || !won || !st->blk || (d->n_tiles && !st->pos) || (d->n_targets && !st->tgt)) return TS_ERR_NULL;
+#pragma omp parallel for schedule(static) num_threads(tso_num_threads())
+  for (int64_t n = 0; n < d->n_boards; ++n) {
+    board b;
+    load_level(d, st, n, &b);
+    load_tiles(d, st->pos, n, &b);
+    won[n] = (uint8_t)tso_is_won(d->n_tiles, b.rows, b.cols, d->n_targets, b.trows, b.tcols, d->multi_color);
+  }
+  return TS_OK;
+}
+
 int32_t tso_encode(const ts_dims *d, const ts_state *st, float *obs) {
   int rc = check_dims(d);
   if (rc) return rc;

@@ -1,0 +1,258 @@
+"""Parity tests proper: the HIP path (through the C-ABI, via tiler_slider_amd) against
+  (1) the golden vectors produced by the reference's own state.py,
+  (2) the CPU oracle on seeded random boards, every output, every step,
+  (3) size-independent properties and a full oracle replay at BASELINE.json's sizes.
+Bit-exact everywhere: positions, counters, flags are integers; observations are small
+integers stored as float32, compared with array_equal (tolerance 0)."""
+import numpy as np
+import pytest
+
+from conftest import golden_groups, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    return torch
+
+
+def _env_from_golden(g, **kw):
+    from tiler_slider_amd import VecTilerSliderEnv
+    S = int(g["size"])
+    B = g["actions"].shape[0]
+    blocked = [[(int(p) // S, int(p) % S) for p in np.flatnonzero(g["blocked"][b])] for b in range(B)]
+    init = [[(int(r), int(c)) for r, c in g["init"][b]] for b in range(B)]
+    tgt = [[(int(r), int(c)) for r, c in g["tgt"][b]] for b in range(B)]
+    return VecTilerSliderEnv(S, blocked, init, tgt, multi_color=bool(g["multi_color"]), **kw)
+
+
+@pytest.mark.parametrize("name", golden_groups())
+def test_hip_replays_reference_golden(torch_cuda, name):
+    """HIP vs the REFERENCE's recorded outputs.  GameState.move has no episode latch, so the
+    done latch is cleared before every step and all boards are compared at all steps."""
+    torch = torch_cuda
+    g = load_golden(name)
+    S, T = int(g["size"]), int(g["n_tiles"])
+    B, L = g["actions"].shape
+    env = _env_from_golden(g, max_steps=2**31 - 1)
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), g["obs0"].astype(np.float32))
+    np.testing.assert_array_equal(env.is_won().cpu().numpy(), g["won0"] != 0)
+    for l in range(L):
+        env._done.zero_()
+        obs, done, info = env.step(torch.from_numpy(g["actions"][:, l].copy()))
+        pos = env.positions.cpu().numpy().T.astype(np.int64).reshape(B, T)
+        np.testing.assert_array_equal(np.stack([pos // S, pos % S], -1), g["pos"][:, l])
+        np.testing.assert_array_equal(info["is_won"].cpu().numpy(), g["won"][:, l] != 0)
+        np.testing.assert_array_equal(obs.cpu().numpy(), g["obs"][:, l].astype(np.float32))
+        np.testing.assert_array_equal(env.is_won().cpu().numpy(), g["won"][:, l] != 0)
+        np.testing.assert_array_equal(env.encode().cpu().numpy(), g["obs"][:, l].astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["s3_t1", "s4_t2_mc", "s5_t2_sc", "s8_t20_mc", "s15_t32_mc"])
+def test_gamestate_adapter_matches_reference_golden(torch_cuda, name):
+    """The one-board GameState adapter (move / is_won / get_state_array / move_to / copy)."""
+    from tiler_slider_amd import GameState
+    g = load_golden(name)
+    S = int(g["size"])
+    for b in range(min(3, g["actions"].shape[0])):
+        blocked = [(int(p) // S, int(p) % S) for p in np.flatnonzero(g["blocked"][b])]
+        st = GameState(S, blocked, [tuple(map(int, x)) for x in g["init"][b]],
+                       [tuple(map(int, x)) for x in g["tgt"][b]], bool(g["multi_color"]))
+        np.testing.assert_array_equal(st.move_to, g["move_to"][b])
+        assert st.is_won() == bool(g["won0"][b])
+        for l in range(g["actions"].shape[1]):
+            won = st.move(GameState.Move.from_int(int(g["actions"][b, l])))
+            assert won == bool(g["won"][b, l])
+            assert st.current_locations == [tuple(map(int, x)) for x in g["pos"][b, l]]
+        arr = st.get_state_array()
+        assert arr.dtype == np.float32 and arr.shape == (S, S, 3)
+        np.testing.assert_array_equal(arr, g["obs"][b, -1].astype(np.float32))
+        twin = st.copy()
+        twin.move(GameState.Move.UP)
+        assert st.current_locations == [tuple(map(int, x)) for x in g["pos"][b, -1]]  # copy is independent
+
+
+# (S, T, K, multi_color, N, max_steps): ragged N (not a multiple of 64 / of 4), every kernel variant
+RANDOM_SHAPES = [
+    (1, 1, 0, False, 67, 5), (2, 1, 1, True, 130, 7), (3, 1, 0, False, 1027, 9), (3, 2, 2, True, 513, 9),
+    (4, 2, 2, True, 4099, 12), (4, 2, 2, False, 4099, 12), (4, 3, 3, False, 1000, 12), (4, 5, 4, True, 777, 30),
+    (5, 2, 3, True, 4099, 12), (5, 2, 3, False, 2049, 12), (5, 7, 5, False, 1500, 40), (6, 1, 6, True, 999, 10),
+    (6, 9, 6, True, 640, 40), (7, 2, 9, False, 1111, 10), (7, 12, 9, True, 321, 40), (8, 2, 12, True, 2050, 10),
+    (8, 30, 10, False, 259, 40), (8, 60, 2, True, 131, 40),
+    (9, 4, 9, True, 1023, 12), (10, 20, 0, False, 515, 40), (12, 16, 20, True, 258, 40), (13, 1, 30, False, 130, 9),
+    (15, 32, 24, True, 1030, 40), (15, 32, 24, False, 259, 40), (16, 40, 30, True, 66, 40), (16, 255, 0, False, 9, 40),
+]
+
+
+@pytest.mark.parametrize("S,T,K,mc,N,max_steps", RANDOM_SHAPES)
+@pytest.mark.parametrize("autoreset", [False, True])
+def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, autoreset):
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=1000 + S * 17 + T)
+    if T >= 2:  # force some solved-at-start and duplicate-target boards into the batch
+        tgt[:, ::7] = init[:, ::7]
+        tgt[1, 3::11] = tgt[0, 3::11]
+    ref = oracle.OracleBatch(S, mc, max_steps, blk, init, tgt)
+    env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps,
+                                        auto_reset=autoreset, with_reward=True, with_onehot=True,
+                                        with_valid_moves=True)
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset())
+    mode = oracle.MODE_AUTORESET if autoreset else oracle.MODE_STRICT
+    for step in range(24):
+        act = oracle.fill_actions(N, seed=77 + S, step_index=step)
+        if step == 5:
+            act[::13] = 9  # invalid action bytes: flagged, board untouched
+        obs, done, info = env.step(torch.from_numpy(act))
+        want = ref.step(act, mode=mode, reward=True, onehot=True, valid=True)
+        ctx = f"S={S} T={T} step={step}"
+        np.testing.assert_array_equal(env.positions.cpu().numpy(), ref.pos, err_msg=ctx)
+        np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+        np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref.step_count, err_msg=ctx)
+        np.testing.assert_array_equal(done.cpu().numpy(), ref.done != 0, err_msg=ctx)
+        np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"], err_msg=ctx)
+        np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
+        np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
+        np.testing.assert_array_equal(env._valid.cpu().numpy(), want["valid"], err_msg=ctx)
+    # stand-alone entry points on the final state
+    np.testing.assert_array_equal(env.get_valid_moves().cpu().numpy(),
+                                  (ref.valid_moves()[:, None] >> np.arange(4)) & 1 != 0)
+    np.testing.assert_array_equal(env.encode().cpu().numpy(), ref.encode())
+    np.testing.assert_array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
+    np.testing.assert_array_equal(env.reward().cpu().numpy(), ref.reward())
+    np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
+    if not autoreset:  # strict mode: some boards ended (wins or max_steps) and were then flagged
+        assert (ref.done != 0).any()
+
+
+def test_mismatched_tile_and_target_counts(torch_cuda, oracle):
+    """len(tiles) != len(targets) (reachable through create_from_string, environment.py:236-288)."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    for S, T, Tt, mc in ((4, 2, 3, True), (4, 3, 1, False), (5, 0, 2, False), (12, 5, 9, True), (12, 9, 5, False)):
+        N = 300
+        blk, init, _ = oracle.generate(S, T, T, 3, N, seed=5)
+        _, _, tgt = oracle.generate(S, Tt, Tt, 0, N, seed=6)
+        ref = oracle.OracleBatch(S, mc, 50, blk, init, tgt)
+        env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=50, with_reward=True,
+                                            with_onehot=True)
+        np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset())
+        for step in range(6):
+            act = oracle.fill_actions(N, seed=8, step_index=step)
+            obs, done, info = env.step(torch.from_numpy(act))
+            want = ref.step(act, reward=True, onehot=True)
+            np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"])
+            np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"])
+            np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"])
+            np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"])
+
+
+def test_generator_and_actions_match_twin(torch_cuda, oracle):
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    for S, T, K in ((3, 1, 0), (4, 2, 2), (5, 2, 3), (8, 20, 10), (15, 32, 24), (16, 100, 50)):
+        N, off = 3001, 12345
+        env = VecTilerSliderEnv.random(N, size=S, num_tiles=T, num_obstacles=K, seed=0x715311DE, board_offset=off)
+        blk, init, tgt = oracle.generate(S, T, T, K, N, seed=0x715311DE, board_offset=off)
+        np.testing.assert_array_equal(env._blk.cpu().numpy().view(np.uint32), blk)
+        np.testing.assert_array_equal(env._init.cpu().numpy(), init)
+        np.testing.assert_array_equal(env._tgt.cpu().numpy(), tgt)
+        # level invariants of the reference factory (tests/test_environment.py:403-417): no overlaps
+        cells = np.concatenate([init, tgt]).astype(np.int64)
+        for n in range(0, N, 97):
+            col = cells[:, n]
+            assert len(set(col.tolist())) == 2 * T
+            assert all(((int(blk[p >> 5, n]) >> (p & 31)) & 1) == 0 for p in col)
+
+
+@pytest.mark.parametrize("S,T,K,N", [(4, 2, 2, 1 << 20), (5, 2, 3, 1 << 20), (15, 32, 24, 1 << 18)])
+def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N):
+    """BASELINE.json configs 1, 2 and 4 at full size: a complete oracle replay of every board for a
+    few steps (the C oracle is fast enough), then properties that do not need the oracle:
+    sliding twice in one direction is idempotent, tile / obstacle counts are conserved in the
+    observation, and autoreset keeps every board live."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    env = VecTilerSliderEnv.random(N, size=S, num_tiles=T, num_obstacles=K, seed=0x715311DE, multi_color=True,
+                                   max_steps=2**30, auto_reset=True, with_reward=True)
+    blk = env._blk.cpu().numpy().view(np.uint32)
+    ref = oracle.OracleBatch(S, True, 2**30, blk, env._init.cpu().numpy(), env._tgt.cpu().numpy())
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset())
+    steps = 6 if S <= 5 else 3
+    for step in range(steps):
+        act = oracle.fill_actions(N, seed=0xAC710005, step_index=step)
+        obs, done, info = env.step(torch.from_numpy(act))
+        want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True)
+        assert np.array_equal(env.positions.cpu().numpy(), ref.pos)
+        assert np.array_equal(info["flags"].cpu().numpy(), want["flags"])
+        assert np.array_equal(info["reward"].cpu().numpy(), want["reward"])
+        assert np.array_equal(obs.cpu().numpy(), want["obs"])
+    # idempotence: the same direction again moves nothing (on boards that were not just reset / won)
+    act = torch.full((N,), 2, dtype=torch.uint8, device=env.device)
+    env.step(act)
+    live = ~env.done
+    before = env.positions.clone()
+    _, _, info = env.step(act)
+    moved_again = (~info["invalid_move"]) & live & ~info["autoreset"]
+    assert int(moved_again.sum()) == 0
+    assert bool((env.positions == before)[:, live & ~info["autoreset"]].all())
+    # conservation: T tiles, K obstacles, T targets per board in the observation
+    obs = env.encode()
+    assert bool(((obs[..., 1] != 0).sum(dim=(1, 2)) == T).all())
+    assert bool((obs[..., 0].sum(dim=(1, 2)) == K).all())
+    assert bool(((obs[..., 2] != 0).sum(dim=(1, 2)) == T).all())
+    # multi_color channel 1 holds each index 1..T exactly once
+    assert bool((obs[..., 1].sum(dim=(1, 2)) == T * (T + 1) // 2).all())
+
+
+def test_strict_mode_raises_like_reference(torch_cuda):
+    torch = torch_cuda
+    from tiler_slider_amd import Move, VecTilerSliderEnv
+    env = VecTilerSliderEnv(3, [[], []], [[(0, 0)], [(0, 0)]], [[(2, 0)], [(2, 2)]], strict=True)
+    with pytest.raises(RuntimeError, match="reset"):
+        env.step([Move.DOWN, Move.DOWN])
+    env.reset()
+    with pytest.raises(TypeError, match="must be a GameState.Move enum"):
+        env.step([0, 1])
+    _, done, info = env.step([Move.DOWN, Move.DOWN])
+    assert done.tolist() == [True, False] and info["success"].tolist() == [True, False]
+    with pytest.raises(RuntimeError, match="Episode is done"):
+        env.step([Move.UP, Move.UP])
+    assert env.positions.cpu().tolist() == [[6, 6]]  # nothing moved by the refused step
+    with pytest.raises(ValueError):
+        env.reset()
+        env.step(torch.tensor([0, 7]))
+
+
+def test_nonstrict_flags_and_step_count_info(torch_cuda):
+    torch = torch_cuda
+    from tiler_slider_amd import Move, VecTilerSliderEnv
+    env = VecTilerSliderEnv(3, [[], []], [[(0, 0)], [(0, 0)]], [[(2, 0)], [(2, 2)]], max_steps=2)
+    env.reset()
+    _, done, info = env.step([Move.DOWN, Move.DOWN])
+    assert info["step_count"].tolist() == [0, 0] and done.tolist() == [True, False]
+    _, done, info = env.step([Move.UP, Move.UP])
+    assert info["stepped_done"].tolist() == [True, False]
+    assert info["timeout"].tolist() == [False, True] and done.tolist() == [True, True]
+    assert info["step_count"].tolist() == [1, 1]
+    assert env.positions.cpu().tolist() == [[6, 0]]
+
+
+def test_factory_levels_on_gpu(torch_cuda):
+    """create_simple_env(seed) levels (SURVEY.md §8c captures) stepped by the HIP path."""
+    from tiler_slider_amd import Move, TilerSliderEnvFactory
+    env = TilerSliderEnvFactory.create_simple_env(size=5, num_tiles=2, num_obstacles=3, seed=42)
+    assert env.blocked_locations == [(1, 3), (3, 1), (0, 0)]
+    assert env.initial_locations == [(4, 3), (2, 1)] and env.target_locations == [(1, 4), (2, 3)]
+    obs = env.reset()
+    assert obs.shape == (5, 5, 3) and obs[..., 0].sum() == 3 and obs[..., 1].sum() == 2
+    _, done, info = env.step(Move.UP)
+    assert env.state.current_locations == [(2, 3), (0, 1)] and info["is_won"] is False
+    vec = TilerSliderEnvFactory.create_vec_env_from_seeds([42, 0, 7], size=5)
+    assert vec.reset().shape == (3, 5, 5, 3)
+    env = TilerSliderEnvFactory.create_from_string("A..a\nX...\n...X\nB.b.", multi_color=True)
+    env.reset()
+    assert env.state.current_locations == [(0, 3), (3, 2)] and env.get_info()["num_targets"] == 2

@@ -1,0 +1,191 @@
+"""Single-board adapters with the reference's exact Python types, running on the HIP path.
+
+`TilerSliderEnv` (ref: explainrl/environment/environment.py:14-194) and `GameState`
+(ref: explainrl/environment/state.py:18-222) keep the reference's constructor signatures,
+attribute names, return types and exceptions, so reference-style drivers (renderers,
+play loops, the reference's own tests) run unchanged.  Each is a one-board
+VecTilerSliderEnv: every transition, win test, legality mask and observation comes from
+the gfx950 kernels; these classes only convert between Python lists and device tensors.
+"""
+import copy
+
+import numpy as np
+import torch
+
+from . import _cabi
+from .levels import pack_levels, unpack_blocked, unpack_cells
+from .moves import ALL_MOVES, Move
+from .vec_env import _DONE_MSG, VecTilerSliderEnv
+
+_NO_LIMIT = 2**31 - 1
+
+
+class GameState:
+    """One board.  `move`, `is_won`, `get_state_array` and `move_to` execute on the GPU."""
+
+    Move = Move
+
+    def __init__(self, size, blocked_locations, initial_locations, target_locations, multi_color=False, *,
+                 device=None):
+        self.size = size
+        self.current_locations = copy.copy(initial_locations)
+        self.target_locations = copy.copy(target_locations)
+        self.multi_color = multi_color
+        self.is_blocked = np.zeros((size, size), dtype=bool)
+        for i, j in blocked_locations:
+            self.is_blocked[i, j] = True
+        self._blocked_locations = [(int(i), int(j)) for i, j in blocked_locations]
+        self._device = device
+        self._vec = VecTilerSliderEnv(size, [self._blocked_locations], [list(self.current_locations)],
+                                      [list(self.target_locations)], multi_color=multi_color, max_steps=_NO_LIMIT,
+                                      device=device)
+        self._vec.reset()
+        self._move_to = None
+
+    # -- state.py:120-170
+    def move(self, move):
+        v = self._vec
+        v._done.zero_()  # GameState has no episode latch: it can keep moving after a win
+        v.step_async(torch.tensor([move.value], dtype=torch.uint8, device=v.device))
+        self.current_locations = unpack_cells(self.size, v.positions[:, 0].cpu().numpy())
+        return bool(int(v._flags[0]) & _cabi.FLAG_IS_WON)
+
+    # -- state.py:172-186
+    def is_won(self):
+        return bool(self._vec.is_won()[0])
+
+    # -- state.py:188-211
+    def get_state_array(self):
+        return self._vec.encode()[0].cpu().numpy()
+
+    # -- state.py:213-222
+    def copy(self):
+        return GameState(self.size, self._blocked_locations, copy.copy(self.current_locations),
+                         copy.copy(self.target_locations), self.multi_color, device=self._device)
+
+    @property
+    def move_to(self):
+        """int array [S, S, 4, 2]: slide destination of a lone tile from every cell in every
+        direction (state.py:75-118).  Not stored by the kernels; computed on demand by sliding
+        4*S*S one-tile boards on the GPU."""
+        if self._move_to is None:
+            S = self.size
+            C = S * S
+            n = 4 * C
+            # raw arrays: the table also has entries for obstacle cells (a cell's own flag is
+            # never read, state.py:84-118), which the level packer would reject as tile cells
+            blk1, _, _ = pack_levels(S, [self._blocked_locations], [[]], [[]])
+            probe = VecTilerSliderEnv.from_arrays(
+                S, np.repeat(blk1, n, axis=1), np.tile(np.arange(C, dtype=np.uint8), 4)[None, :],
+                np.zeros((1, n), np.uint8), max_steps=_NO_LIMIT, device=self._device)
+            probe.reset()
+            probe.step(torch.arange(4, dtype=torch.uint8).repeat_interleave(C))
+            dest = probe.positions[0].cpu().numpy().reshape(4, S, S)
+            table = np.empty((S, S, 4, 2), dtype=int)
+            for d in range(4):
+                table[:, :, d, 0] = dest[d] // S
+                table[:, :, d, 1] = dest[d] % S
+            self._move_to = table
+        return self._move_to
+
+
+class _BoardView:
+    """`env.state` of the adapter: the attributes reference drivers read (display.py:59-70)."""
+
+    def __init__(self, env):
+        self._env = env
+        self.size = env.size
+        self.multi_color = env.multi_color
+        self.target_locations = list(env.target_locations)
+        self.is_blocked = unpack_blocked(env.size, env._vec._blk[:, 0].cpu().numpy().view(np.uint32))
+        self.current_locations = []
+        self.refresh()
+
+    def refresh(self):
+        self.current_locations = unpack_cells(self.size, self._env._vec.positions[:, 0].cpu().numpy())
+
+    def is_won(self):
+        return bool(self._env._vec.is_won()[0])
+
+    def get_state_array(self):
+        return self._env._vec.encode()[0].cpu().numpy()
+
+    def copy(self):
+        blocked = [(int(r), int(c)) for r, c in zip(*np.nonzero(self.is_blocked))]
+        return GameState(self.size, blocked, list(self.current_locations), list(self.target_locations),
+                         self.multi_color, device=self._env._device)
+
+
+class TilerSliderEnv:
+    """Drop-in for the reference environment: same arguments, attributes, returns, errors."""
+
+    def __init__(self, size=None, blocked_locations=None, initial_locations=None, target_locations=None,
+                 multi_color=False, max_steps=100, *, device=None):
+        self.size = size
+        self.blocked_locations = blocked_locations or []
+        self.initial_locations = initial_locations or []
+        self.target_locations = target_locations or []
+        self.multi_color = multi_color
+        self.max_steps = max_steps
+        self.state = None
+        self.step_count = 0
+        self.done = False
+        self.observation_shape = (size, size, 3) if size else None
+        self._device = device
+        self._vec = None
+
+    @classmethod
+    def from_level(cls, level, max_steps=100, **kw):
+        """ref: environment.py:61-80; `level` has the five ImageProcessed fields."""
+        return cls(size=level.size, blocked_locations=level.blocked_locations,
+                   initial_locations=level.initial_locations, target_locations=level.target_locations,
+                   multi_color=level.multiple_colors, max_steps=max_steps, **kw)
+
+    def reset(self):
+        if self._vec is None:
+            self._vec = VecTilerSliderEnv(self.size, [self.blocked_locations], [self.initial_locations],
+                                          [self.target_locations], multi_color=self.multi_color,
+                                          max_steps=self.max_steps, device=self._device)
+        obs = self._vec.reset()[0].cpu().numpy()
+        self.state = _BoardView(self)
+        self.step_count = 0
+        self.done = False
+        return obs
+
+    def step(self, move):
+        if self.done:
+            raise RuntimeError(_DONE_MSG)
+        if not isinstance(move, Move):
+            raise TypeError(f"Action must be a GameState.Move enum, got {type(move)}")
+        if self._vec is None or self.state is None:
+            raise RuntimeError("Call reset() before step().")
+        v = self._vec
+        v.step_async(torch.tensor([move.value], dtype=torch.uint8, device=v.device))
+        flags = int(v._flags[0])  # device -> host: this adapter is synchronous like the reference
+        self.state.refresh()
+        info = {"is_won": bool(flags & _cabi.FLAG_IS_WON), "step_count": self.step_count,
+                "invalid_move": bool(flags & _cabi.FLAG_INVALID_MOVE)}
+        if flags & _cabi.FLAG_SUCCESS:
+            info["success"] = True
+        if flags & _cabi.FLAG_TIMEOUT:
+            info["timeout"] = True
+        self.step_count = int(v.step_count[0])
+        self.done = bool(v._done[0])
+        return v._obs[0].cpu().numpy(), self.done, info
+
+    def close(self):
+        self.state = None
+
+    def get_valid_moves(self):
+        if self.state is None:
+            return []
+        mask = self._vec.get_valid_moves()[0].cpu().numpy()
+        return [m for m in ALL_MOVES if mask[m.value]]
+
+    def get_info(self):
+        if self.state is None:
+            return {"initialized": False}
+        return {"initialized": True, "size": self.size, "step_count": self.step_count, "max_steps": self.max_steps,
+                "done": self.done, "is_won": self.state.is_won(), "num_tiles": len(self.state.current_locations),
+                "num_targets": len(self.state.target_locations), "multi_color": self.multi_color,
+                "valid_moves": self.get_valid_moves()}

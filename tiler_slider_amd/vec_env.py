@@ -1,0 +1,329 @@
+"""VecTilerSliderEnv — N independent Tiler-Slider boards stepped by one HIP kernel launch.
+
+Same method names and return order as the reference's single-board environment
+(ref: explainrl/environment/environment.py:14-194 TilerSliderEnv), batched:
+
+    reset()              -> obs  float32 [N, S, S, 3]                      (environment.py:82-98)
+    step(actions)        -> (obs, done bool [N], info)                     (environment.py:100-143)
+    get_valid_moves()    -> bool [N, 4], column d = Move(d)                (environment.py:149-171)
+    get_info()           -> dict                                           (environment.py:173-194)
+    close()                                                                (environment.py:145-147)
+
+PyTorch-ROCm tensors are the device buffers; all arithmetic happens in
+csrc/ts_kernels.hip through the C-ABI of include/tiler_slider.h.  There is no CPU path.
+"""
+import ctypes as C
+from collections.abc import Mapping
+
+import numpy as np
+import torch
+
+from . import _cabi
+from .levels import blk_words, pack_levels
+from .moves import Move
+
+_DONE_MSG = "Episode is done. Call reset() to start a new episode."  # environment.py:114
+
+
+class StepInfo(Mapping):
+    """The per-step info dict of the reference, as tensors, decoded lazily from the flag byte.
+
+    Keys: is_won, invalid_move, success, timeout (bool [N]), step_count (int32 [N], the value
+    BEFORE this step's increment, as in environment.py:128), plus the vector-env extras
+    stepped_done, autoreset, bad_action and the raw `flags` byte.  Optional kernel outputs
+    (reward, onehot, valid_moves) appear when the environment was built with them."""
+
+    _BITS = {"is_won": _cabi.FLAG_IS_WON, "invalid_move": _cabi.FLAG_INVALID_MOVE, "success": _cabi.FLAG_SUCCESS,
+             "timeout": _cabi.FLAG_TIMEOUT, "stepped_done": _cabi.FLAG_STEPPED_DONE,
+             "autoreset": _cabi.FLAG_AUTORESET, "bad_action": _cabi.FLAG_BAD_ACTION}
+
+    def __init__(self, flags, step_count, extras):
+        self._flags, self._step_count, self._extras = flags, step_count, extras
+
+    def __getitem__(self, key):
+        if key == "flags":
+            return self._flags
+        if key in self._BITS:
+            return (self._flags & self._BITS[key]) != 0
+        if key == "step_count":
+            frozen = _cabi.FLAG_STEPPED_DONE | _cabi.FLAG_AUTORESET | _cabi.FLAG_BAD_ACTION
+            return self._step_count - ((self._flags & frozen) == 0).to(torch.int32)
+        return self._extras[key]
+
+    def __iter__(self):
+        yield from ("is_won", "step_count", "invalid_move", "success", "timeout", "stepped_done", "autoreset",
+                    "bad_action", "flags")
+        yield from self._extras
+
+    def __len__(self):
+        return 9 + len(self._extras)
+
+
+class VecTilerSliderEnv:
+    """N boards of one shape (size, tile count, target count, multi_color) on one GPU."""
+
+    def __init__(self, size, blocked_locations=None, initial_locations=None, target_locations=None,
+                 multi_color=False, max_steps=100, *, device=None, strict=False, auto_reset=False,
+                 with_reward=False, with_onehot=False, with_valid_moves=False):
+        """blocked/initial/target_locations: one list of (row, col) per board.
+
+        strict      : raise the reference's RuntimeError when any board is stepped after done
+                      (costs a device sync per step).  Default: such boards are left untouched
+                      and flagged `stepped_done`.
+        auto_reset  : boards that are done when step() is called are reset in place instead
+                      (flag `autoreset`); their returned observation is the reset observation.
+        """
+        n = len(initial_locations or [])
+        blocked_locations = blocked_locations if blocked_locations is not None else [[] for _ in range(n)]
+        target_locations = target_locations if target_locations is not None else [[] for _ in range(n)]
+        blk, init, tgt = pack_levels(size, blocked_locations, initial_locations or [], target_locations)
+        self._setup(size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
+                    with_onehot, with_valid_moves)
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_arrays(cls, size, blk, init, tgt, multi_color=False, max_steps=100, **kw):
+        """Packed level arrays (numpy or torch) in the device layout: blk [W,N] 32-bit words,
+        init uint8 [T,N], tgt uint8 [Tt,N]."""
+        self = cls.__new__(cls)
+        self._setup(size, blk, init, tgt, multi_color, max_steps, kw.pop("device", None), kw.pop("strict", False),
+                    kw.pop("auto_reset", False), kw.pop("with_reward", False), kw.pop("with_onehot", False),
+                    kw.pop("with_valid_moves", False))
+        if kw:
+            raise TypeError(f"unexpected arguments {sorted(kw)}")
+        return self
+
+    @classmethod
+    def from_levels(cls, levels, max_steps=100, **kw):
+        """A list of level records (ref: environment.py:61-80 from_level, one per board)."""
+        levels = list(levels)
+        if not levels:
+            raise ValueError("from_levels needs at least one level")
+        size, mc = levels[0].size, bool(levels[0].multiple_colors)
+        if any(l.size != size or bool(l.multiple_colors) != mc for l in levels):
+            raise ValueError("all levels of a batch must share size and multiple_colors")
+        return cls(size, [l.blocked_locations for l in levels], [l.initial_locations for l in levels],
+                   [l.target_locations for l in levels], multi_color=mc, max_steps=max_steps, **kw)
+
+    @classmethod
+    def random(cls, n_boards, size=5, num_tiles=2, num_obstacles=3, seed=0, multi_color=False, max_steps=100,
+               board_offset=0, **kw):
+        """Random levels generated ON THE DEVICE with the distribution of the reference factory
+        (ref: environment.py:202-234): obstacles, tiles and targets on distinct uniformly random
+        cells.  Board n is a pure function of (seed, board_offset + n)."""
+        device = _resolve_device(kw.get("device"))
+        W = blk_words(size)
+        blk = torch.zeros((W, n_boards), dtype=torch.int32, device=device)
+        init = torch.zeros((num_tiles, n_boards), dtype=torch.uint8, device=device)
+        tgt = torch.zeros((num_tiles, n_boards), dtype=torch.uint8, device=device)
+        dims = _cabi.Dims(n_boards, size, num_tiles, num_tiles, int(bool(multi_color)), max_steps, 0)
+        st = _cabi.State(None, init.data_ptr(), tgt.data_ptr(), blk.data_ptr(), None, None)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _cabi.check(_cabi.lib().ts_generate(C.byref(dims), C.byref(st), C.c_uint64(seed & (2**64 - 1)),
+                                                board_offset, num_obstacles, stream), "ts_generate")
+        return cls.from_arrays(size, blk, init, tgt, multi_color=multi_color, max_steps=max_steps, **kw)
+
+    # ------------------------------------------------------------------ setup
+    def _setup(self, size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
+               with_onehot, with_valid_moves):
+        L = _cabi.lib()  # raises when the HIP library is missing: no fallback
+        self.device = _resolve_device(device)
+        self.size, self.multi_color, self.max_steps = int(size), bool(multi_color), int(max_steps)
+        self.strict, self.auto_reset = bool(strict), bool(auto_reset)
+        self._blk = _to_device(blk, torch.int32, self.device)
+        self._init = _to_device(init, torch.uint8, self.device)
+        self._tgt = _to_device(tgt, torch.uint8, self.device)
+        W = blk_words(self.size)
+        if self._blk.dim() != 2 or self._blk.shape[0] != W:
+            raise ValueError(f"blk must have shape [{W}, N]")
+        self.num_envs = N = self._blk.shape[1]
+        if self._init.dim() != 2 or self._tgt.dim() != 2 or self._init.shape[1] != N or self._tgt.shape[1] != N:
+            raise ValueError("init / tgt must have shape [T, N] / [Tt, N]")
+        self.n_tiles, self.n_targets = self._init.shape[0], self._tgt.shape[0]
+        self._dims = _cabi.Dims(N, self.size, self.n_tiles, self.n_targets, int(self.multi_color), self.max_steps, 0)
+        _cabi.check(L.ts_check_dims(C.byref(self._dims)), "VecTilerSliderEnv")
+        dev = self.device
+        self._pos = self._init.clone()
+        self._step_count = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._flags = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._actions = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._obs = torch.zeros((N, self.size, self.size, 3), dtype=torch.float32, device=dev)
+        self.onehot_channels = L.ts_onehot_channels(C.byref(self._dims))
+        self._reward = torch.zeros(N, dtype=torch.int32, device=dev) if with_reward else None
+        self._onehot = (torch.zeros((N, self.onehot_channels, self.size, self.size), dtype=torch.float32, device=dev)
+                        if with_onehot else None)
+        self._valid = torch.zeros(N, dtype=torch.uint8, device=dev) if with_valid_moves else None
+        self._state = _cabi.State(_ptr(self._pos), _ptr(self._init), _ptr(self._tgt), _ptr(self._blk),
+                                  _ptr(self._step_count), _ptr(self._done))
+        self._out = _cabi.StepOut(_ptr(self._flags), _ptr(self._obs), _ptr(self._reward), _ptr(self._onehot),
+                                  _ptr(self._valid))
+        self._mode = _cabi.MODE_AUTORESET if self.auto_reset else _cabi.MODE_STRICT
+        self.observation_shape = (self.size, self.size, 3)  # per board, environment.py:59
+        self._started = False
+        self._closed = False
+
+    # ------------------------------------------------------------------ reference API
+    def reset(self):
+        """All boards back to their level's initial cells; returns the observation tensor."""
+        self._require_open()
+        self._call("ts_reset", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
+        self._started = True
+        return self._obs
+
+    def step(self, actions):
+        """actions: uint8/int tensor [N] of Move values, a numpy array, or a list of Move.
+        Returns (obs, done, info).  `obs` is the environment's own buffer, overwritten by the
+        next step()/reset() — clone it to keep it."""
+        self._require_open()
+        if not self._started:
+            raise RuntimeError("Call reset() before step().")
+        act = self._stage_actions(actions)
+        if self.strict and not self.auto_reset and bool(self._done.any()):
+            raise RuntimeError(_DONE_MSG)
+        self.step_async(act)
+        if self.strict and bool((self._flags & _cabi.FLAG_BAD_ACTION).any()):
+            raise ValueError("actions must be Move values 0..3")  # state.py:43-45
+        return self._obs, self._done.view(torch.bool), self._info()
+
+    def step_async(self, act=None):
+        """The bare launch: one ts_step on the current stream, no validation, no sync.
+        `act` is a uint8 device tensor [N] (default: the env's own action buffer)."""
+        a = self._actions if act is None else act
+        self._call("ts_step", C.byref(self._dims), C.byref(self._state), a.data_ptr(), self._mode,
+                   C.byref(self._out))
+
+    def get_valid_moves(self):
+        """bool [N, 4]: column d is True where Move(d) would change the board."""
+        self._require_open()
+        mask = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        if not self._started:  # environment.py:156-157: [] before reset
+            return torch.zeros((self.num_envs, 4), dtype=torch.bool, device=self.device)
+        self._call("ts_valid_moves", C.byref(self._dims), C.byref(self._state), mask.data_ptr())
+        return _expand_mask(mask)
+
+    def get_info(self):
+        """ref: environment.py:173-194, batched."""
+        if not self._started or self._closed:
+            return {"initialized": False}
+        return {"initialized": True, "size": self.size, "step_count": self._step_count.clone(),
+                "max_steps": self.max_steps, "done": self._done.view(torch.bool).clone(), "is_won": self.is_won(),
+                "num_tiles": self.n_tiles, "num_targets": self.n_targets, "multi_color": self.multi_color,
+                "valid_moves": self.get_valid_moves()}
+
+    def close(self):
+        self._started = False
+        self._closed = True
+
+    # ------------------------------------------------------------------ extras
+    @property
+    def step_count(self):
+        return self._step_count
+
+    @property
+    def done(self):
+        return self._done.view(torch.bool)
+
+    @property
+    def positions(self):
+        """uint8 [T, N] current cell ids (r * size + c)."""
+        return self._pos
+
+    def encode(self, out=None):
+        """The reference observation of the current boards (state.py:188-211)."""
+        out = torch.empty_like(self._obs) if out is None else out
+        self._call("ts_encode", C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        return out
+
+    def encode_onehot(self, out=None):
+        """Build-defined one-hot planes float32 [N, Ch, S, S] (see include/tiler_slider.h)."""
+        if out is None:
+            out = torch.empty((self.num_envs, self.onehot_channels, self.size, self.size), dtype=torch.float32,
+                              device=self.device)
+        self._call("ts_encode_onehot", C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        return out
+
+    def reward(self, out=None):
+        """Build-defined Manhattan reward int32 [N] (see include/tiler_slider.h)."""
+        out = torch.empty(self.num_envs, dtype=torch.int32, device=self.device) if out is None else out
+        self._call("ts_reward", C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        return out
+
+    def is_won(self):
+        """bool [N]: GameState.is_won() of the current boards (state.py:172-186)."""
+        won = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        self._call("ts_is_won", C.byref(self._dims), C.byref(self._state), won.data_ptr())
+        return won.view(torch.bool)
+
+    # ------------------------------------------------------------------ internals
+    def _info(self):
+        extras = {}
+        if self._reward is not None:
+            extras["reward"] = self._reward
+        if self._onehot is not None:
+            extras["onehot"] = self._onehot
+        if self._valid is not None:
+            extras["valid_moves"] = _expand_mask(self._valid)
+        return StepInfo(self._flags, self._step_count, extras)
+
+    def _stage_actions(self, actions):
+        if isinstance(actions, torch.Tensor):
+            if actions.dtype == torch.bool or actions.is_floating_point() or actions.is_complex():
+                raise TypeError(f"actions tensor must hold integers, got {actions.dtype}")
+            if actions.shape != (self.num_envs,):
+                raise ValueError(f"actions must have shape ({self.num_envs},)")
+            if actions.dtype == torch.uint8 and actions.device == self.device and actions.is_contiguous():
+                return actions
+            self._actions.copy_(actions.to(self.device, non_blocking=True).clamp(0, 255))
+            return self._actions
+        if isinstance(actions, np.ndarray):
+            if actions.dtype.kind not in "iu":
+                raise TypeError(f"actions array must hold integers, got {actions.dtype}")
+            return self._stage_actions(torch.from_numpy(np.ascontiguousarray(actions.clip(0, 255).astype(np.uint8))))
+        vals = []
+        for a in actions:
+            if not isinstance(a, Move):  # environment.py:116-117
+                raise TypeError(f"Action must be a GameState.Move enum, got {type(a)}")
+            vals.append(a.value)
+        return self._stage_actions(torch.tensor(vals, dtype=torch.uint8))
+
+    def _call(self, name, *args):
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _cabi.check(getattr(_cabi.lib(), name)(*args, stream), name)
+
+    def _require_open(self):
+        if self._closed:
+            raise RuntimeError("environment is closed")
+
+
+def _resolve_device(device):
+    if not torch.cuda.is_available():
+        raise RuntimeError("tiler_slider_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(f"device must be a cuda (ROCm) device, got {dev}")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    return dev
+
+
+def _to_device(a, dtype, device):
+    if isinstance(a, np.ndarray):
+        if dtype == torch.int32 and a.dtype == np.uint32:
+            a = a.view(np.int32)
+        a = torch.from_numpy(np.ascontiguousarray(a))
+    if a.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {a.dtype}")
+    return a.to(device).contiguous()
+
+
+def _ptr(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _expand_mask(mask):
+    shifts = torch.arange(4, device=mask.device, dtype=torch.uint8)
+    return ((mask[:, None] >> shifts[None, :]) & 1).to(torch.bool)
