@@ -92,7 +92,11 @@ RANDOM_SHAPES = [
 def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, autoreset):
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv
-    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=1000 + S * 17 + T)
+    if K + 2 * T <= S * S:
+        blk, init, tgt = oracle.generate(S, T, T, K, N, seed=1000 + S * 17 + T)
+    else:  # dense boards: targets drawn on their own (they may then sit under tiles or obstacles)
+        blk, init, _ = oracle.generate(S, T, 0, K, N, seed=1000 + S * 17 + T)
+        _, _, tgt = oracle.generate(S, 0, T, 0, N, seed=2000 + S * 17 + T)
     if T >= 2:  # force some solved-at-start and duplicate-target boards into the batch
         tgt[:, ::7] = init[:, ::7]
         tgt[1, 3::11] = tgt[0, 3::11]
