@@ -48,11 +48,24 @@ def algorithmic_bytes_per_board_step(size, tiles, onehot, reward, multi_color=Tr
     return read + write
 
 
+def host_cpu_share():
+    """Cores this process may actually use: the cgroup CPU quota if there is one, else the
+    scheduler affinity (a GPU box hands each GPU's job a share of the host, not all of it)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(cfg, budget_s=10.0):
     """The CPU oracle (a C port of the reference algorithm, OpenMP over boards) on the SAME
     synthetic boards and action stream, on this box's host cores.  Reported, never the target."""
-    import numpy as np  # noqa: F401
     from oracle import binding as orc
+    orc.lib().tso_set_num_threads(host_cpu_share())
     n = min(cfg["boards"], 1 << 20)
     blk, init, tgt = orc.generate(cfg["size"], cfg["tiles"], cfg["tiles"], cfg["obstacles"], n, seed=LEVEL_SEED)
     env = orc.OracleBatch(cfg["size"], True, 2**30, blk, init, tgt)

@@ -128,8 +128,8 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     np.testing.assert_array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
     np.testing.assert_array_equal(env.reward().cpu().numpy(), ref.reward())
     np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
-    if not autoreset:  # strict mode: some boards ended (wins or max_steps) and were then flagged
-        assert (ref.done != 0).any()
+    if not autoreset and max_steps < 24:  # strict mode: every board timed out and was then flagged
+        assert (ref.done != 0).all()
 
 
 def test_mismatched_tile_and_target_counts(torch_cuda, oracle):
@@ -194,15 +194,15 @@ def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N):
         assert np.array_equal(info["flags"].cpu().numpy(), want["flags"])
         assert np.array_equal(info["reward"].cpu().numpy(), want["reward"])
         assert np.array_equal(obs.cpu().numpy(), want["obs"])
-    # idempotence: the same direction again moves nothing (on boards that were not just reset / won)
+    # idempotence: a board that was just slid LEFT does not change when slid LEFT again
     act = torch.full((N,), 2, dtype=torch.uint8, device=env.device)
-    env.step(act)
-    live = ~env.done
+    _, _, info1 = env.step(act)
+    slid = ~info1["autoreset"] & ~env.done  # slid by that step (not reset by it) and still live
     before = env.positions.clone()
-    _, _, info = env.step(act)
-    moved_again = (~info["invalid_move"]) & live & ~info["autoreset"]
-    assert int(moved_again.sum()) == 0
-    assert bool((env.positions == before)[:, live & ~info["autoreset"]].all())
+    _, _, info2 = env.step(act)
+    assert int(slid.sum()) > N // 2
+    assert bool(info2["invalid_move"][slid].all())
+    assert bool((env.positions == before)[:, slid].all())
     # conservation: T tiles, K obstacles, T targets per board in the observation
     obs = env.encode()
     assert bool(((obs[..., 1] != 0).sum(dim=(1, 2)) == T).all())
