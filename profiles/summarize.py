@@ -12,6 +12,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import os
 import shutil
 
@@ -43,7 +44,7 @@ def main():
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if a.kernel in r["Kernel_Name"]:
-                agg[(r["Kernel_Name"].split("(")[0][-60:] + "...", r["Counter_Name"], r["Grid_Size"], r["VGPR_Count"],
+                agg[((re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"]) or [r["Kernel_Name"][:60]])[0], r["Counter_Name"], r["Grid_Size"], r["VGPR_Count"],
                      r["LDS_Block_Size"])].append(float(r["Counter_Value"]))
         lines += [f"## rocprofv3 --pmc ({os.path.basename(d.rstrip('/'))})", "",
                   "| kernel | counter | launches | mean per launch | as bytes (KiB x 1024) | grid | VGPR | LDS/block |", "|---|---|---|---|---|---|---|---|"]
