@@ -11,7 +11,8 @@
 //   * S <= 8  (k_small): ONE BOARD PER LANE, the whole board as a 32/64-bit bitboard in a
 //     register; a wave owns 64 consecutive boards.  SoA state loads/stores are coalesced
 //     (lane n <-> board n).
-//   * S 9..16 (k_large): 16 LANES PER BOARD, obstacle / tile line masks in LDS.
+//   * S 9..16 (k_large): 2..16 LANES PER BOARD (chosen per launch), obstacle / tile line
+//     masks in LDS.
 //   * observation: each wave builds a byte image [boards][S*S*3] of its boards in LDS, then
 //     streams it out as float4 (one ds_read_b32 + 4 v_cvt_f32_ubyteN + one 16-B global
 //     store per lane): the LDS image is the transpose from "lane = board" to "lane = 16
@@ -23,6 +24,33 @@
 
 #include "../../include/tiler_slider.h"
 #include "ts_core.h"
+
+// Tunables (defaults are the shipped configuration; tools/variant_bench.py builds A/B variants
+// by overriding them with -D).
+#ifndef TS_EMIT_UNROLL
+#define TS_EMIT_UNROLL 4
+#endif
+#ifndef TS_NT_THRESHOLD_MB  // launches that write more than this use nontemporal stores
+#define TS_NT_THRESHOLD_MB 256
+#endif
+#ifndef TS_SMALL_MIN_WAVES  // __launch_bounds__ 2nd argument (waves per SIMD) of k_small; 0 = unset
+#define TS_SMALL_MIN_WAVES 0
+#endif
+#ifndef TS_EARLY_LOADS
+#define TS_EARLY_LOADS 1
+#endif
+#ifndef TS_LARGE_GSHIFT  // log2(lanes per board) of k_large; -1 = chosen per launch
+#define TS_LARGE_GSHIFT -1
+#endif
+#ifndef TS_ABLATE  // development only: 1 = skip the observation stores, 2 = skip the state stores
+#define TS_ABLATE 0
+#endif
+#ifndef TS_XCD_REMAP
+#define TS_XCD_REMAP 1
+#endif
+#ifndef TS_WAVES_PER_BLOCK
+#define TS_WAVES_PER_BLOCK 4
+#endif
 
 namespace {
 
@@ -49,6 +77,9 @@ struct KArgs {
   uint32_t lds_wave_bytes;  // LDS carve of one wave (multiple of 16)
   uint32_t lds_stage_off;   // offset of the staging area inside the carve (multiple of 16)
   int32_t onehot_ch;
+  uint32_t nt;  // nontemporal observation stores
+  uint32_t oh_boards;   // one-hot byte image: boards per chunk (0 = evaluate per float)
+  uint32_t lds_oh_off;  // offset of that image inside the wave's carve
 };
 
 // Orders LDS traffic between the lanes of ONE wave.  The hardware executes a wave's DS
@@ -60,19 +91,45 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float4 bytes_to_f4(uint32_t w) {
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // one 16-B register quad
+
+__device__ __forceinline__ f32x4 bytes_to_f4(uint32_t w) {
   // each conversion is one v_cvt_f32_ubyteN
-  return make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24));
+  f32x4 v;
+  v.x = (float)(w & 0xffu);
+  v.y = (float)((w >> 8) & 0xffu);
+  v.z = (float)((w >> 16) & 0xffu);
+  v.w = (float)(w >> 24);
+  return v;
+}
+
+// NT = nontemporal: for launches whose output cannot stay in the 256 MiB Infinity Cache the
+// streaming hint is worth +17 % (5.0 -> 5.9 TB/s at 4M 4x4 boards); for cache-resident
+// launches it costs 12 % (33.7 -> 37.9 us at 1M boards).  Chosen per launch on the host.
+template <bool NT>
+__device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
+  if constexpr (NT)
+    __builtin_nontemporal_store(v, dst);
+  else
+    *dst = v;
 }
 
 // Streams `nfl` bytes of an LDS byte image out as float32, 16 B per lane per instruction.
 // `dst` is 16-B aligned; img is 16-B aligned.
-__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane) {
+__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane, bool nt) {
   const int nf4 = nfl >> 2;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
-  float4 *d4 = reinterpret_cast<float4 *>(dst);
-#pragma unroll 4
-  for (int q = lane; q < nf4; q += kWave) d4[q] = bytes_to_f4(w[q]);
+  f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
+#if TS_ABLATE == 1
+  if (nfl == -12345)  // never true: keeps the code, drops the traffic
+#endif
+  if (nt) {
+#pragma unroll TS_EMIT_UNROLL
+    for (int q = lane; q < nf4; q += kWave) store_f4<true>(&d4[q], bytes_to_f4(w[q]));
+  } else {
+#pragma unroll TS_EMIT_UNROLL
+    for (int q = lane; q < nf4; q += kWave) store_f4<false>(&d4[q], bytes_to_f4(w[q]));
+  }
   const int tail = nfl & 3;  // only on the last, partial tile of odd-sized boards
   if (lane < tail) dst[nf4 * 4 + lane] = (float)img[nf4 * 4 + lane];
 }
@@ -90,8 +147,19 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 // k_small: S <= 8, one board per lane.  TFIX > 0: n_tiles == n_targets == TFIX, positions
 // live in registers; TFIX == 0: any tile count, positions staged in LDS.
 // ------------------------------------------------------------------------------------------
-template <int S, int TFIX>
-__global__ __launch_bounds__(256) void k_small(const KArgs a) {
+#define TS_SMALL_THREADS (TS_WAVES_PER_BLOCK * 64 > 256 ? TS_WAVES_PER_BLOCK * 64 : 256)
+#if TS_SMALL_MIN_WAVES > 0
+#define TS_SMALL_BOUNDS __launch_bounds__(TS_SMALL_THREADS, TS_SMALL_MIN_WAVES)
+#else
+#define TS_SMALL_BOUNDS __launch_bounds__(TS_SMALL_THREADS)
+#endif
+
+// EXTRAS = false compiles the optional outputs (legality mask, reward, one-hot) out, so the
+// plain step / reset / encode path does not carry their registers and code.
+constexpr int kSmallBatch = 8;  // global loads in flight per lane in the any-T tile / target loops
+
+template <int S, int TFIX, bool EXTRAS>
+__global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   using BB = ts::Bitboard<S>;
   using M = typename BB::mask_t;
   constexpr int C = BB::C;
@@ -118,7 +186,7 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
   M *st_tgm = st_occ + kWave;                // [64] target mask
   unsigned char *st_np = stage + 3 * kWave * sizeof(uint64_t);  // [T][64] post-move cells
   unsigned char *st_tg = st_np + (size_t)T * kWave;             // [Tt][64] target cells
-  const bool need_stage = (TFIX == 0) || a.onehot != nullptr;
+  const bool need_stage = (TFIX == 0) || (EXTRAS && a.onehot != nullptr && a.oh_boards == 0);
 
   // ---- per-board scalars ----
   M blk = 0;
@@ -156,17 +224,46 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
   int p[TR], q[TR], tg[TR];
   M occ = 0;
   if constexpr (TFIX > 0) {
+#if TS_EARLY_LOADS
+    // The current cells are loaded without waiting for `done` (which decides between pos and
+    // init): one dependent memory round trip less on the common path; only boards that are
+    // being reset (rare in a step, all in ts_reset) issue the second load.
+    const bool all_reset = a.op == OP_RESET;
+#pragma unroll
+    for (int t = 0; t < TFIX; ++t) {
+      p[t] = (live && !all_reset) ? (int)a.pos[(int64_t)t * N + n] : t;
+      tg[t] = live ? min((int)a.tgt[(int64_t)t * N + n], C - 1) : t;
+    }
+    if (kind == 2 && live) {
+#pragma unroll
+      for (int t = 0; t < TFIX; ++t) p[t] = (int)a.init[(int64_t)t * N + n];
+    }
+#pragma unroll
+    for (int t = 0; t < TFIX; ++t) {
+      p[t] = min(p[t], C - 1);  // clamp: malformed ids stay in-board
+      occ |= M(1) << p[t];
+    }
+#else
 #pragma unroll
     for (int t = 0; t < TFIX; ++t) {
       p[t] = live ? min((int)src[(int64_t)t * N + n], C - 1) : t;  // clamp: malformed ids stay in-board
       tg[t] = live ? min((int)a.tgt[(int64_t)t * N + n], C - 1) : t;
       occ |= M(1) << p[t];
     }
+#endif
   } else {
-    for (int t = 0; t < T; ++t) {
-      const int pt = live ? min((int)src[(int64_t)t * N + n], C - 1) : 0;
-      st_np[t * kWave + lane] = (unsigned char)pt;
-      occ |= M(1) << pt;
+    for (int t0 = 0; t0 < T; t0 += kSmallBatch) {  // loads issued kSmallBatch at a time (see k_large)
+      int v[kSmallBatch];
+#pragma unroll
+      for (int u = 0; u < kSmallBatch; ++u) v[u] = (live && t0 + u < T) ? (int)src[(int64_t)(t0 + u) * N + n] : 0;
+#pragma unroll
+      for (int u = 0; u < kSmallBatch; ++u) {
+        if (t0 + u < T) {
+          const int pt = min(v[u], C - 1);
+          st_np[(t0 + u) * kWave + lane] = (unsigned char)pt;
+          occ |= M(1) << pt;
+        }
+      }
     }
   }
 
@@ -192,11 +289,20 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
       st_np[t * kWave + lane] = (unsigned char)qt;
       if (live && kind != 1) a.pos[(int64_t)t * N + n] = (uint8_t)qt;
     }
-    for (int j = 0; j < Tt; ++j) {
-      const int tj = live ? min((int)a.tgt[(int64_t)j * N + n], C - 1) : 0;
-      st_tg[j * kWave + lane] = (unsigned char)tj;
-      tgm |= M(1) << tj;
-      if (j < T) ordered &= (int)st_np[j * kWave + lane] == tj;
+    for (int j0 = 0; j0 < Tt; j0 += kSmallBatch) {
+      int v[kSmallBatch];
+#pragma unroll
+      for (int u = 0; u < kSmallBatch; ++u) v[u] = (live && j0 + u < Tt) ? (int)a.tgt[(int64_t)(j0 + u) * N + n] : 0;
+#pragma unroll
+      for (int u = 0; u < kSmallBatch; ++u) {
+        const int j = j0 + u;
+        if (j < Tt) {
+          const int tj = min(v[u], C - 1);
+          st_tg[j * kWave + lane] = (unsigned char)tj;
+          tgm |= M(1) << tj;
+          if (j < T) ordered &= (int)st_np[j * kWave + lane] == tj;
+        }
+      }
     }
   }
   if constexpr (TFIX > 0) {
@@ -236,7 +342,7 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
   if (live && a.flags) a.flags[n] = (uint8_t)flags;
 
   // ---- legality mask of the post-move board (environment.py:149-171) ----
-  if (a.valid) {
+  if (EXTRAS && a.valid) {
     uint32_t vm = 0;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -256,7 +362,7 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
   }
 
   // ---- build-defined Manhattan reward ----
-  if (a.reward) {
+  if (EXTRAS && a.reward) {
     int sum = 0;
     auto np_at = [&](int t) -> int {
       if constexpr (TFIX > 0) {
@@ -317,11 +423,42 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
       }
     }
     wave_sync();
-    emit_bytes_as_f32(img, a.obs + n0 * (3 * C), nb * 3 * C, lane);
+    emit_bytes_as_f32(img, a.obs + n0 * (3 * C), nb * 3 * C, lane, a.nt != 0);
   }
 
-  // ---- build-defined one-hot planes [board][Ch][S][S], straight from the staged cells ----
-  if (a.onehot) {
+  // ---- build-defined one-hot planes [board][Ch][S][S] ----
+  if (EXTRAS && a.onehot && a.oh_boards > 0) {
+    // Byte image of `oh_boards` boards at a time ([board][Ch][S*S], one byte per output float),
+    // built by the boards' own lanes, streamed out by the whole wave like the observation.
+    const int D = a.onehot_ch * C;  // bytes per board in the image = floats per board in HBM
+    unsigned char *oimg = img + a.lds_oh_off;
+    const int nbc = (int)a.oh_boards;  // 4..64, a power of two: chunk outputs stay 16-B aligned
+    const int img_bytes = (nbc * D + 15) & ~15;
+    for (int c0 = 0; c0 < nb; c0 += nbc) {
+      wave_sync();
+      for (int off = lane * 16; off < img_bytes; off += kWave * 16) *reinterpret_cast<uint4 *>(oimg + off) = make_uint4(0, 0, 0, 0);
+      wave_sync();
+      const int rel = lane - c0;
+      if (live && rel >= 0 && rel < nbc) {
+        unsigned char *my = oimg + rel * D;
+        for (M m = blk; m; m &= m - 1) my[ts::lsb(m)] = 1;
+        if constexpr (TFIX > 0) {
+#pragma unroll
+          for (int t = 0; t < TFIX; ++t) my[(mc ? 1 + t : 1) * C + q[t]] = 1;
+#pragma unroll
+          for (int t = 0; t < TFIX; ++t) my[(mc ? 1 + TFIX + t : 2) * C + tg[t]] = 1;
+        } else {
+          for (int t = 0; t < T; ++t) my[(mc ? 1 + t : 1) * C + st_np[t * kWave + lane]] = 1;
+          for (int j = 0; j < Tt; ++j) my[(mc ? 1 + T + j : 2) * C + st_tg[j * kWave + lane]] = 1;
+        }
+      }
+      wave_sync();
+      const int nbb = (nb - c0) < nbc ? (nb - c0) : nbc;
+      emit_bytes_as_f32(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.nt != 0);
+    }
+  } else if (EXTRAS && a.onehot) {
+    // Fallback for very many planes (one board's image above the LDS budget): every output
+    // float is evaluated from the staged cells.
     wave_sync();
     const int Ch = a.onehot_ch;
     const int D = Ch * C;  // floats per board
@@ -353,7 +490,10 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
           ++bb;
         }
       }
-      reinterpret_cast<float4 *>(dst)[f4] = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.nt)
+        store_f4<true>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
+      else
+        store_f4<false>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
       r += 4 * kWave;
       while (r >= D) {
         r -= D;
@@ -369,47 +509,69 @@ __global__ __launch_bounds__(256) void k_small(const KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_large: S in 9..16, 16 lanes per board (4 boards per wave).  Obstacles and tiles are kept
-// as per-row and per-column bit masks in LDS; a tile's new index along its lane comes from
-// ts::slide_line on the lane's two masks.
+// k_large: S in 9..16.  G = 2^gshift lanes cooperate on one board (64/G boards per wave); the
+// host picks G so that a wave's LDS carve stays near 16 KiB (G = 4 at 15x15 with 32 tiles).
+// Obstacles, tiles and targets are kept as line masks in LDS: word i of a LineMasks array
+// holds row i's cells in bits 0..15 and column i's cells in bits 16..31; a tile's new index
+// along its lane comes from ts::slide_line on the lane's obstacle and tile masks.  Lanes of a
+// group share the board's tiles round-robin (tile t -> lane t mod G); masks are accumulated
+// with LDS atomic OR; group-wide AND/OR go through __ballot.
 // ------------------------------------------------------------------------------------------
-constexpr int kGroup = 16;                    // lanes per board
-constexpr int kBoardsPerWave = kWave / kGroup;  // 4
+// Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only).  A wave
+// of k_large touches just 4..32 consecutive bytes of each SoA state row, so with the plain
+// blockIdx order every 128-B line of pos/tgt/blk would be read and partially written through
+// all 8 non-coherent L2s.  This bijective remap gives the blocks that share an XCD one contiguous
+// range of boards, so each line lives in one L2 and leaves it as one full-line write.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks) {
+#if TS_XCD_REMAP
+  const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#else
+  return bid;
+#endif
+}
 
-struct LargeLds {  // per board, all uint32
-  uint32_t rowB[16], colB[16];  // obstacle bits of row r / column c
-  uint32_t rowO[16], colO[16];  // tile bits before the move
-  uint32_t rowN[16], colN[16];  // tile bits after the move
-  uint32_t rowT[16];            // target bits per row
-  uint32_t words[8];            // packed obstacle bitmask as loaded
-  uint32_t red[8];              // small reductions
+constexpr int kLoadBatch = 8;  // global loads in flight per lane in the tile / target loops
+
+struct LineMasks {
+  uint32_t B[16];  // obstacles
+  uint32_t O[16];  // tiles before the move
+  uint32_t Nw[16]; // tiles after the move
+  uint32_t Tm[16]; // targets
 };
 
-__global__ __launch_bounds__(256) void k_large(const KArgs a, const int S) {
+__global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const int gshift, const uint32_t invS) {
+  // x / S for x < 256 without the ~25-instruction runtime division: invS = ceil(65536 / S) makes
+  // (x * invS) >> 16 exact for S <= 16 (the error term x / 65536 stays below 1/S).
+  auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
+  auto cell_of = [&](int r, int c) -> int { return (int)__umul24((uint32_t)r, (uint32_t)S) + c; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int g = lane >> 4;           // board slot inside the wave
-  const int j = lane & (kGroup - 1);  // lane inside the board's group
-  const int64_t n0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * kBoardsPerWave;
+  const int G = 1 << gshift;     // lanes per board
+  const int BPW = kWave >> gshift;  // boards per wave
+  const int g = lane >> gshift;  // board slot inside the wave
+  const int j = lane & (G - 1);  // lane inside the board's group
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * BPW;
   if (n0 >= a.N) return;  // wave-uniform
   const int64_t N = a.N;
   const int64_t n = n0 + g;
   const bool live = n < N;
-  const int nb = (N - n0) < kBoardsPerWave ? (int)(N - n0) : kBoardsPerWave;
+  const int nb = (N - n0) < BPW ? (int)(N - n0) : BPW;
   const int C = S * S, W = (C + 31) >> 5;
   const int T = a.T, Tt = a.Tt;
   const bool mc = a.mc != 0;
   const uint32_t rowmask = (1u << S) - 1;
+  const uint64_t gmask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (g << gshift);
 
-  unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;  // [4][3C] bytes, flat
+  unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;  // [BPW][3C] bytes, flat
   unsigned char *stage = img + a.lds_stage_off;
-  LargeLds *L = reinterpret_cast<LargeLds *>(stage) + g;
-  unsigned char *st_base = stage + kBoardsPerWave * sizeof(LargeLds);
-  unsigned char *st_np = st_base + (size_t)g * (T + Tt);  // [T] cells (pre-move, then post-move)
-  unsigned char *st_tg = st_np + T;                        // [Tt]
+  LineMasks *L0 = reinterpret_cast<LineMasks *>(stage);
+  LineMasks *L = L0 + g;
+  unsigned char *cells0 = stage + (size_t)BPW * sizeof(LineMasks);
+  unsigned char *cells = cells0 + (size_t)g * (T + Tt);  // [T] tile cells, then [Tt] target cells
 
-  // ---- per-board scalars (every lane of the group loads the same address: one request) ----
+  // ---- per-board scalars (the group's lanes load the same address: one request) ----
   uint32_t action = 0, done_in = 0;
   int32_t sc = 0;
   if (live && a.op == OP_STEP) {
@@ -417,7 +579,7 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S) {
     sc = a.step_count[n];
     action = a.actions[n];
   }
-  int kind;
+  int kind;  // 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells
   uint32_t flags = 0;
   if (a.op == OP_RESET) {
     kind = 2;
@@ -432,80 +594,131 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S) {
   } else {
     kind = 0;
   }
-  const uint8_t *src = kind == 2 ? a.init : a.pos;
   const int dir = (int)(action & 3u);
   const bool vert = dir < 2, neg = (dir & 1) == 0;
 
-  // ---- obstacle line masks ----
-  if (j < 8) L->words[j] = (live && j < W) ? a.blk[(int64_t)j * N + n] : 0u;
-  L->rowO[j] = 0;
-  L->colO[j] = 0;
-  L->rowN[j] = 0;
-  L->colN[j] = 0;
-  L->rowT[j] = 0;
-  wave_sync();
+  // Which masks this launch needs (all wave-uniform except `vert`, which is per board):
+  //   column halves        : vertical slides, and the legality mask (all four directions)
+  //   post-move tiles  Nw  : set-equality win test (rows), legality mask (rows + columns)
+  //   targets          Tm  : set-equality win test
+  const bool need_new = !mc || a.valid != nullptr;
+  const bool need_cols = a.valid != nullptr || (kind == 0 && vert);
+
+  // ---- clear the line masks; park the packed obstacle words in the (not yet used) image ----
   {
-    uint32_t rb = 0;
-    if (j < S) {
-      const int bit0 = j * S, w0 = bit0 >> 5, sh = bit0 & 31;
-      uint64_t two = (uint64_t)L->words[w0];
-      if (w0 + 1 < 8) two |= (uint64_t)L->words[w0 + 1] << 32;
-      rb = (uint32_t)(two >> sh) & rowmask;
+    uint4 *z = reinterpret_cast<uint4 *>(L0);
+    const int n16 = BPW * (int)sizeof(LineMasks) / 16;
+    for (int i = lane; i < n16; i += kWave) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  uint32_t *words = reinterpret_cast<uint32_t *>(img) + g * 8;
+  for (int w = j; w < 8; w += G) words[w] = (live && w < W) ? a.blk[(int64_t)w * N + n] : 0u;
+  wave_sync();
+  for (int r = j; r < S; r += G) {
+    const int bit0 = r * S, w0 = bit0 >> 5, sh = bit0 & 31;
+    uint64_t two = (uint64_t)words[w0];
+    if (w0 + 1 < 8) two |= (uint64_t)words[w0 + 1] << 32;
+    const uint32_t rb = (uint32_t)(two >> sh) & rowmask;
+    if (rb) atomicOr(&L->B[r], rb);
+    if (need_cols)
+      for (uint32_t m = rb; m; m &= m - 1) atomicOr(&L->B[ts::lsb(m)], 1u << (16 + r));
+  }
+
+  // ---- pass 1: pre-move cells into LDS, line occupancy by atomic OR ----
+  // Global loads go out kLoadBatch at a time before anything waits on them: a loop of
+  // load -> use -> load would pay one memory round trip per tile (measured: 303 us at 16
+  // tiles per lane vs 152 us at 2).
+  // The current cells are loaded before `done` (which decides between pos and init) has
+  // arrived; only boards being reset (rare in a step, all of them in ts_reset) load again.
+  const bool all_reset = a.op == OP_RESET;
+  // row t of an SoA array starts t * N bytes in: walk it with 64-bit pointer increments (one
+  // multiply per loop nest) instead of a 64-bit multiply per access
+  const int64_t lane_off = (int64_t)j * N + n;   // row j, this board
+  const int64_t group_stride = N << gshift;      // G rows further
+  for (int t0 = j; t0 < T; t0 += G * kLoadBatch) {
+    int v[kLoadBatch];
+    const int64_t off0 = lane_off + (int64_t)(t0 - j) * N;
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int t = t0 + u * G;
+      v[u] = (live && t < T && !all_reset) ? (int)a.pos[off0 + u * group_stride] : 0;
     }
-    L->rowB[j] = rb;
+    if (kind == 2 && live) {
+#pragma unroll
+      for (int u = 0; u < kLoadBatch; ++u) {
+        const int t = t0 + u * G;
+        if (t < T) v[u] = (int)a.init[off0 + u * group_stride];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int t = t0 + u * G;
+      if (t < T) {
+        const int pt = min(v[u], C - 1);
+        cells[t] = (unsigned char)pt;
+        if (kind == 0) {  // occupancy of the lanes the move runs along
+          const int r = div_s(pt), c = pt - (int)__umul24((uint32_t)r, (uint32_t)S);
+          if (vert)
+            atomicOr(&L->O[c], 1u << (16 + r));
+          else
+            atomicOr(&L->O[r], 1u << c);
+        }
+      }
+    }
+  }
+  for (int t0 = j; t0 < Tt; t0 += G * kLoadBatch) {
+    int v[kLoadBatch];
+    const int64_t off0 = lane_off + (int64_t)(t0 - j) * N;
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int t = t0 + u * G;
+      v[u] = (live && t < Tt) ? (int)a.tgt[off0 + u * group_stride] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < kLoadBatch; ++u) {
+      const int t = t0 + u * G;
+      if (t < Tt) {
+        const int tj = min(v[u], C - 1);
+        cells[T + t] = (unsigned char)tj;
+        if (!mc) {
+          const int r = div_s(tj), c = tj - (int)__umul24((uint32_t)r, (uint32_t)S);
+          atomicOr(&L->Tm[r], 1u << c);
+        }
+      }
+    }
   }
   wave_sync();
-  {
-    uint32_t cb = 0;
-    for (int r = 0; r < S; ++r) cb |= ((L->rowB[r] >> j) & 1u) << r;
-    L->colB[j] = j < S ? cb : 0u;
-  }
 
-  // ---- pass 1: pre-move cells into LDS, occupancy by atomic OR ----
-  for (int t = j; t < T; t += kGroup) {
-    const int pt = live ? min((int)src[(int64_t)t * N + n], C - 1) : 0;
-    st_np[t] = (unsigned char)pt;
-    const int r = pt / S, c = pt - r * S;
-    atomicOr(&L->rowO[r], 1u << c);
-    atomicOr(&L->colO[c], 1u << r);
-  }
-  for (int t = j; t < Tt; t += kGroup) {
-    const int tj = live ? min((int)a.tgt[(int64_t)t * N + n], C - 1) : 0;
-    st_tg[t] = (unsigned char)tj;
-    const int r = tj / S, c = tj - r * S;
-    atomicOr(&L->rowT[r], 1u << c);
-  }
-  wave_sync();
-
-  // ---- pass 2: slide ----
+  // ---- pass 2: slide (state.py:120-170) ----
   bool same = true, ordered = true;
-  for (int t = j; t < T; t += kGroup) {
-    const int pt = st_np[t];
-    int r = pt / S, c = pt - r * S;
+  uint8_t *pos_out = a.pos + lane_off;
+  for (int t = j; t < T; t += G, pos_out += group_stride) {
+    const int pt = cells[t];
+    int r = div_s(pt), c = pt - (int)__umul24((uint32_t)r, (uint32_t)S);
     if (kind == 0) {
       if (vert)
-        r = ts::slide_line(r, L->colB[c], L->colO[c], S, neg);
+        r = ts::slide_line(r, L->B[c] >> 16, L->O[c] >> 16, S, neg);
       else
-        c = ts::slide_line(c, L->rowB[r], L->rowO[r], S, neg);
+        c = ts::slide_line(c, L->B[r] & 0xffffu, L->O[r] & 0xffffu, S, neg);
     }
-    const int qt = r * S + c;
+    const int qt = cell_of(r, c);
     same &= qt == pt;
-    if (t < Tt) ordered &= qt == (int)st_tg[t];
-    atomicOr(&L->rowN[r], 1u << c);
-    atomicOr(&L->colN[c], 1u << r);
-    if (live && kind != 1) a.pos[(int64_t)t * N + n] = (uint8_t)qt;
-    // every lane rewrites only its own tiles; readers of st_np[t] for other t sit behind wave_sync
-    st_np[t] = (unsigned char)qt;
+    if (t < Tt) ordered &= qt == (int)cells[T + t];
+    if (need_new) {
+      atomicOr(&L->Nw[r], 1u << c);
+      if (a.valid) atomicOr(&L->Nw[c], 1u << (16 + r));
+    }
+    if (live && kind != 1) *pos_out = (uint8_t)qt;
+    cells[t] = (unsigned char)qt;  // only this lane reads cells[t] before the next wave_sync
   }
   wave_sync();
-  const bool rows_equal = j < S ? (L->rowN[j] == L->rowT[j]) : true;
-  // group-wide AND via ballot: bits [16g, 16g+16) belong to this board
-  const uint64_t gmask = 0xffffull << (16 * g);
+  bool rows_equal = true;
+  if (!mc)
+    for (int r = j; r < S; r += G) rows_equal &= ((L->Nw[r] ^ L->Tm[r]) & 0xffffu) == 0;
   const bool all_same = (__ballot(same) & gmask) == gmask;
   const bool all_ordered = (T == Tt) && ((__ballot(ordered) & gmask) == gmask);
   const bool all_rows = (__ballot(rows_equal) & gmask) == gmask;
 
-  const bool won = mc ? all_ordered : all_rows;
+  const bool won = mc ? all_ordered : all_rows;  // state.py:172-186
   if (a.op == OP_OBSERVE && won) flags |= TS_FLAG_IS_WON;
   if (kind == 0) {
     if (won) flags |= TS_FLAG_IS_WON | TS_FLAG_SUCCESS;
@@ -526,17 +739,17 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S) {
   }
   if (live && j == 0 && a.flags) a.flags[n] = (uint8_t)flags;
 
-  // ---- legality mask ----
+  // ---- legality mask of the post-move board (environment.py:149-171) ----
   if (a.valid) {
     uint32_t vm = 0;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       bool moved = false;
-      for (int t = j; t < T; t += kGroup) {
-        const int qt = st_np[t];
-        const int r = qt / S, c = qt - r * S;
-        const int x = d < 2 ? ts::slide_line(r, L->colB[c], L->colN[c], S, (d & 1) == 0)
-                            : ts::slide_line(c, L->rowB[r], L->rowN[r], S, (d & 1) == 0);
+      for (int t = j; t < T; t += G) {
+        const int qt = cells[t];
+        const int r = div_s(qt), c = qt - (int)__umul24((uint32_t)r, (uint32_t)S);
+        const int x = d < 2 ? ts::slide_line(r, L->B[c] >> 16, L->Nw[c] >> 16, S, (d & 1) == 0)
+                            : ts::slide_line(c, L->B[r] & 0xffffu, L->Nw[r] & 0xffffu, S, (d & 1) == 0);
         moved |= x != (d < 2 ? r : c);
       }
       vm |= ((__ballot(moved) & gmask) != 0 ? 1u : 0u) << d;
@@ -549,66 +762,79 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S) {
     int sum = 0;
     if (mc) {
       const int m = T < Tt ? T : Tt;
-      for (int i = j; i < m; i += kGroup) {
-        const int x = st_np[i], y = st_tg[i];
-        sum += abs(x / S - y / S) + abs(x % S - y % S);
+      for (int i = j; i < m; i += G) {
+        const int x = cells[i], y = cells[T + i];
+        {
+          const int xr = div_s(x), yr = div_s(y);
+          sum += abs(xr - yr) + abs((x - cell_of(xr, 0)) - (y - cell_of(yr, 0)));
+        }
       }
     } else if (Tt > 0) {
-      for (int i = j; i < T; i += kGroup) {
-        const int x = st_np[i];
+      for (int i = j; i < T; i += G) {
+        const int x = cells[i];
         int best = 1 << 30;
         for (int k = 0; k < Tt; ++k) {
-          const int y = st_tg[k];
-          const int dist = abs(x / S - y / S) + abs(x % S - y % S);
+          const int y = cells[T + k];
+          const int xr = div_s(x), yr = div_s(y);
+          const int dist = abs(xr - yr) + abs((x - cell_of(xr, 0)) - (y - cell_of(yr, 0)));
           best = dist < best ? dist : best;
         }
         sum += best;
       }
     }
-#pragma unroll
-    for (int o = kGroup / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kGroup);
+    for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);  // stays inside the group: o < G
     if (live && j == 0) a.reward[n] = -sum;
   }
 
-  // ---- observation through the LDS byte image ----
+  // ---- observation (state.py:188-211) through the LDS byte image ----
   if (a.obs) {
-    const int img_bytes = (kBoardsPerWave * 3 * C + 15) & ~15;
+    wave_sync();  // the parked obstacle words are dead now
+    const int img_bytes = (BPW * 3 * C + 15) & ~15;
     for (int off = lane * 16; off < img_bytes; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
     wave_sync();
     unsigned char *my = img + g * (3 * C);
     if (live) {
-      if (j < S)
-        for (uint32_t m = L->rowB[j]; m; m &= m - 1) my[3 * (j * S + ts::lsb(m))] = 1;
-      for (int t = j; t < T; t += kGroup) my[3 * st_np[t] + 1] = (unsigned char)(mc ? t + 1 : 1);
+      for (int r = j; r < S; r += G)
+        for (uint32_t m = L->B[r] & 0xffffu; m; m &= m - 1) my[3 * cell_of(r, ts::lsb(m))] = 1;
+      for (int t = j; t < T; t += G) my[3 * cells[t] + 1] = (unsigned char)(mc ? t + 1 : 1);
+      for (int t = j; t < Tt; t += G) my[3 * cells[T + t] + 2] = (unsigned char)(mc ? t + 1 : 1);
     }
-    // targets in index order, one per instruction: with duplicate target cells the highest
-    // index must win (state.py:209-211), which lanes writing in parallel cannot promise
-    for (int t = 0; t < Tt; ++t)
-      if (live && j == 0) my[3 * st_tg[t] + 2] = (unsigned char)(mc ? t + 1 : 1);
     wave_sync();
-    emit_bytes_as_f32(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
+    if (mc) {
+      // Duplicate target cells: the highest index must win (state.py:209-211), which lanes
+      // writing in parallel cannot promise.  Every lane reads its targets' bytes back; a byte
+      // that is not the lane's own index exposes a duplicate, and then one lane rewrites the
+      // board's target channel in index order.  (Levels from the factories never have any.)
+      bool clash = false;
+      if (live)
+        for (int t = j; t < Tt; t += G) clash |= my[3 * cells[T + t] + 2] != (unsigned char)(t + 1);
+      if ((__ballot(clash) & gmask) != 0) {
+        wave_sync();
+        if (live && j == 0)
+          for (int t = 0; t < Tt; ++t) my[3 * cells[T + t] + 2] = (unsigned char)(t + 1);
+      }
+      wave_sync();
+    }
+    emit_bytes_as_f32(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.nt != 0);
   }
 
-  // ---- build-defined one-hot planes ----
+  // ---- build-defined one-hot planes: every output float evaluated from the staged cells ----
   if (a.onehot) {
     wave_sync();
     const int Ch = a.onehot_ch;
     const int D = Ch * C;
     float *dst = a.onehot + n0 * (int64_t)D;
     const int nfl = nb * D;
-    const LargeLds *L0 = reinterpret_cast<const LargeLds *>(stage);
     auto value = [&](int b, int r) -> float {
       const int plane = r / C, cell = r - plane * C;
-      const int cr = cell / S, cc = cell - cr * S;
-      const unsigned char *bnp = st_base + (size_t)b * (T + Tt);
+      const int cr = div_s(cell), cc = cell - cell_of(cr, 0);
       uint32_t bit;
       if (plane == 0) {
-        bit = (L0[b].rowB[cr] >> cc) & 1u;
+        bit = (L0[b].B[cr] >> cc) & 1u;
       } else if (mc) {
-        const int at = bnp[plane - 1];  // tiles then targets, contiguous
-        bit = at == cell;
+        bit = (int)cells0[(size_t)b * (T + Tt) + plane - 1] == cell;  // tiles then targets, contiguous
       } else {
-        bit = ((plane == 1 ? L0[b].rowN[cr] : L0[b].rowT[cr]) >> cc) & 1u;
+        bit = ((plane == 1 ? L0[b].Nw[cr] : L0[b].Tm[cr]) >> cc) & 1u;
       }
       return bit ? 1.0f : 0.0f;
     };
@@ -625,7 +851,10 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S) {
           ++bb;
         }
       }
-      reinterpret_cast<float4 *>(dst)[f4] = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.nt)
+        store_f4<true>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
+      else
+        store_f4<false>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
       r += 4 * kWave;
       while (r >= D) {
         r -= D;
@@ -706,19 +935,24 @@ int32_t onehot_channels(const ts_dims *d) { return d->multi_color ? 1 + d->n_til
 
 using SmallKernel = void (*)(const KArgs);
 
-template <int TFIX>
+template <int TFIX, bool EXTRAS>
 SmallKernel small_kernel_for(int S) {
   switch (S) {
-    case 1: return k_small<1, TFIX>;
-    case 2: return k_small<2, TFIX>;
-    case 3: return k_small<3, TFIX>;
-    case 4: return k_small<4, TFIX>;
-    case 5: return k_small<5, TFIX>;
-    case 6: return k_small<6, TFIX>;
-    case 7: return k_small<7, TFIX>;
-    case 8: return k_small<8, TFIX>;
+    case 1: return k_small<1, TFIX, EXTRAS>;
+    case 2: return k_small<2, TFIX, EXTRAS>;
+    case 3: return k_small<3, TFIX, EXTRAS>;
+    case 4: return k_small<4, TFIX, EXTRAS>;
+    case 5: return k_small<5, TFIX, EXTRAS>;
+    case 6: return k_small<6, TFIX, EXTRAS>;
+    case 7: return k_small<7, TFIX, EXTRAS>;
+    case 8: return k_small<8, TFIX, EXTRAS>;
     default: return nullptr;
   }
+}
+
+template <bool EXTRAS>
+SmallKernel small_kernel(int S, int tfix) {
+  return tfix == 1 ? small_kernel_for<1, EXTRAS>(S) : tfix == 2 ? small_kernel_for<2, EXTRAS>(S) : small_kernel_for<0, EXTRAS>(S);
 }
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -754,29 +988,51 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   a.mc = d->multi_color;
   a.max_steps = d->max_steps;
   a.onehot_ch = onehot_channels(d);
+  {
+    const uint64_t per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);
+    a.nt = per_board * (uint64_t)d->n_boards > (uint64_t)TS_NT_THRESHOLD_MB * 1024ull * 1024ull ? 1u : 0u;
+  }
   hipStream_t hs = (hipStream_t)stream;
 
   if (S <= 8) {
     const int tfix = (T == Tt && (T == 1 || T == 2)) ? T : 0;
-    const bool need_stage = tfix == 0 || a.onehot;
+    if (a.onehot) {  // largest power-of-two chunk of boards whose one-hot byte image fits 16 KiB
+      for (uint32_t nbc = kWave; nbc >= 4 && !a.oh_boards; nbc >>= 1)
+        if (align16(nbc * (uint32_t)(a.onehot_ch * C)) <= 16u * 1024u) a.oh_boards = nbc;
+    }
+    const bool need_stage = tfix == 0 || (a.onehot && !a.oh_boards);
     a.lds_stage_off = align16((uint32_t)(kWave * 3 * C));
-    a.lds_wave_bytes = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
-    int waves = 4;
-    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > 48u * 1024u) waves >>= 1;
+    a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
+    a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C));
+    int waves = TS_WAVES_PER_BLOCK;
+    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > 64u * 1024u) waves >>= 1;
     const int64_t boards_per_block = (int64_t)waves * kWave;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-    SmallKernel k = tfix == 1 ? small_kernel_for<1>(S) : tfix == 2 ? small_kernel_for<2>(S) : small_kernel_for<0>(S);
+    const bool extras = a.valid || a.reward || a.onehot;
+    SmallKernel k = extras ? small_kernel<true>(S, tfix) : small_kernel<false>(S, tfix);
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a);
   } else {
-    a.lds_stage_off = align16((uint32_t)(kBoardsPerWave * 3 * C));
-    a.lds_wave_bytes = a.lds_stage_off + align16((uint32_t)(kBoardsPerWave * (sizeof(LargeLds) + T + Tt)));
-    int waves = 4;
-    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > 48u * 1024u) waves >>= 1;
-    const int64_t boards_per_block = (int64_t)waves * kBoardsPerWave;
+    const uint32_t per_board = (uint32_t)(3 * C + T + Tt) + (uint32_t)sizeof(LineMasks);
+    // Measured at 15x15 / 32 tiles (744 MB per launch): 16 lanes per board 129 us, 8: 132 us,
+    // 4: 147..167 us, 2: 250 us — few tiles per lane (short dependent chains) and a small LDS
+    // carve (more resident waves) beat fewer instructions per board.  Hence: about two tiles
+    // per lane, and at most ~8 KiB of LDS per wave.
+    int gshift = TS_LARGE_GSHIFT;
+    if (gshift < 0) {
+      gshift = 1;
+      while (gshift < 4 && ((uint32_t)(kWave >> gshift) * per_board > 8u * 1024u || (T + 1) / 2 > (1 << gshift))) ++gshift;
+    }
+    const int bpw = kWave >> gshift;
+    a.lds_stage_off = align16((uint32_t)(bpw * 3 * C));
+    a.lds_wave_bytes = a.lds_stage_off + align16((uint32_t)(bpw * (sizeof(LineMasks) + T + Tt)));
+    int waves = TS_WAVES_PER_BLOCK > 4 ? 4 : TS_WAVES_PER_BLOCK;
+    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > 64u * 1024u) waves >>= 1;
+    const int64_t boards_per_block = (int64_t)waves * bpw;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-    hipLaunchKernelGGL(k_large, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S);
+    hipLaunchKernelGGL(k_large, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, gshift,
+                       (uint32_t)((65536 + S - 1) / S));
   }
   return finish_launch();
 }
