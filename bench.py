@@ -32,6 +32,8 @@ CONFIGS = {
     "cfg1": dict(size=4, tiles=2, obstacles=2, boards=1 << 20, onehot=False, reward=False),
     "cfg2": dict(size=5, tiles=2, obstacles=3, boards=1 << 20, onehot=True, reward=True),
     "cfg4": dict(size=15, tiles=32, obstacles=24, boards=1 << 18, onehot=False, reward=False),
+    # not in BASELINE.json: exercises the any-tile-count path of the one-lane-per-board kernel
+    "s8t20": dict(size=8, tiles=20, obstacles=10, boards=1 << 19, onehot=False, reward=False),
 }
 
 

@@ -79,6 +79,7 @@ def test_gamestate_adapter_matches_reference_golden(torch_cuda, name):
 RANDOM_SHAPES = [
     (1, 1, 0, False, 67, 5), (2, 1, 1, True, 130, 7), (3, 1, 0, False, 1027, 9), (3, 2, 2, True, 513, 9),
     (4, 2, 2, True, 4099, 12), (4, 2, 2, False, 4099, 12), (4, 3, 3, False, 1000, 12), (4, 5, 4, True, 777, 30),
+    (2, 4, 0, False, 200, 6), (5, 4, 3, True, 1025, 12), (8, 3, 20, False, 700, 12),
     (5, 2, 3, True, 4099, 12), (5, 2, 3, False, 2049, 12), (5, 7, 5, False, 1500, 40), (6, 1, 6, True, 999, 10),
     (6, 9, 6, True, 640, 40), (7, 2, 9, False, 1111, 10), (7, 12, 9, True, 321, 40), (8, 2, 12, True, 2050, 10),
     (8, 30, 10, False, 259, 40), (8, 60, 2, True, 131, 40),
@@ -260,3 +261,48 @@ def test_factory_levels_on_gpu(torch_cuda):
     env = TilerSliderEnvFactory.create_from_string("A..a\nX...\n...X\nB.b.", multi_color=True)
     env.reset()
     assert env.state.current_locations == [(0, 3), (3, 2)] and env.get_info()["num_targets"] == 2
+
+
+def test_gym_wrapper_and_hipgraph_replay(torch_cuda, oracle):
+    """Five-tuple adapter, and step_async captured into a hipGraph replays bit-exactly."""
+    torch = torch_cuda
+    from tiler_slider_amd import GymVecTilerSlider, VecTilerSliderEnv
+    N = 5000
+    blk, init, tgt = oracle.generate(4, 2, 2, 2, N, seed=3)
+    env = VecTilerSliderEnv.from_arrays(4, blk, init, tgt, multi_color=True, max_steps=3, with_reward=True,
+                                        auto_reset=True)
+    ref = oracle.OracleBatch(4, True, 3, blk, init, tgt)
+    g = GymVecTilerSlider(env, success_bonus=10.0)
+    obs, info = g.reset()
+    np.testing.assert_array_equal(obs.cpu().numpy(), ref.reset())
+    for step in range(5):
+        act = oracle.fill_actions(N, seed=1, step_index=step)
+        obs, reward, terminated, truncated, info = g.step(torch.from_numpy(act))
+        want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True)
+        f = want["flags"]
+        np.testing.assert_array_equal(terminated.cpu().numpy(), (f & oracle.FLAG_SUCCESS) != 0)
+        np.testing.assert_array_equal(truncated.cpu().numpy(),
+                                      ((f & oracle.FLAG_TIMEOUT) != 0) & ((f & oracle.FLAG_SUCCESS) == 0))
+        np.testing.assert_array_equal(reward.cpu().numpy(),
+                                      want["reward"].astype(np.float32) + 10.0 * ((f & oracle.FLAG_SUCCESS) != 0))
+    assert g.action_masks().shape == (N, 4)
+    # hipGraph: capture 4 steps with fixed action buffers, replay twice, compare with the oracle
+    acts = [torch.from_numpy(oracle.fill_actions(N, seed=2, step_index=i)).to(env.device) for i in range(4)]
+    env.reset()
+    ref.reset()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            for a in acts:
+                env.step_async(a)
+    env.reset()
+    for rep in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        for a in acts:
+            want = ref.step(a.cpu().numpy(), mode=oracle.MODE_AUTORESET)
+        np.testing.assert_array_equal(env.positions.cpu().numpy(), ref.pos)
+        np.testing.assert_array_equal(env._obs.cpu().numpy(), want["obs"])
+        np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref.step_count)

@@ -9,6 +9,7 @@ if it is missing (no CPU fallback).
 from ._cabi import TilerSliderLibraryError, build_library
 from .env import GameState, TilerSliderEnv
 from .factory import TilerSliderEnvFactory, simple_level
+from .gym_wrapper import GymVecTilerSlider
 from .levels import Level, pack_levels, parse_board_string
 from .moves import Move
 from .render import TextRender
@@ -16,5 +17,5 @@ from .vec_env import StepInfo, VecTilerSliderEnv
 
 __version__ = "0.1.0"
 __all__ = ["GameState", "Move", "TilerSliderEnv", "TilerSliderEnvFactory", "TextRender", "VecTilerSliderEnv",
-           "StepInfo", "Level", "pack_levels", "parse_board_string", "simple_level", "build_library",
+           "StepInfo", "GymVecTilerSlider", "Level", "pack_levels", "parse_board_string", "simple_level", "build_library",
            "TilerSliderLibraryError"]

@@ -144,7 +144,7 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_small: S <= 8, one board per lane.  TFIX > 0: n_tiles == n_targets == TFIX, positions
+// k_small: S <= 8, one board per lane.  TFIX in 1..4: n_tiles == n_targets == TFIX, positions
 // live in registers; TFIX == 0: any tile count, positions staged in LDS.
 // ------------------------------------------------------------------------------------------
 #define TS_SMALL_THREADS (TS_WAVES_PER_BLOCK * 64 > 256 ? TS_WAVES_PER_BLOCK * 64 : 256)
@@ -952,7 +952,13 @@ SmallKernel small_kernel_for(int S) {
 
 template <bool EXTRAS>
 SmallKernel small_kernel(int S, int tfix) {
-  return tfix == 1 ? small_kernel_for<1, EXTRAS>(S) : tfix == 2 ? small_kernel_for<2, EXTRAS>(S) : small_kernel_for<0, EXTRAS>(S);
+  switch (tfix) {
+    case 1: return small_kernel_for<1, EXTRAS>(S);
+    case 2: return small_kernel_for<2, EXTRAS>(S);
+    case 3: return small_kernel_for<3, EXTRAS>(S);
+    case 4: return small_kernel_for<4, EXTRAS>(S);
+    default: return small_kernel_for<0, EXTRAS>(S);
+  }
 }
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -995,7 +1001,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   hipStream_t hs = (hipStream_t)stream;
 
   if (S <= 8) {
-    const int tfix = (T == Tt && (T == 1 || T == 2)) ? T : 0;
+    const int tfix = (T == Tt && T >= 1 && T <= 4 && T <= C) ? T : 0;  // cells in registers
     if (a.onehot) {  // largest power-of-two chunk of boards whose one-hot byte image fits 16 KiB
       for (uint32_t nbc = kWave; nbc >= 4 && !a.oh_boards; nbc >>= 1)
         if (align16(nbc * (uint32_t)(a.onehot_ch * C)) <= 16u * 1024u) a.oh_boards = nbc;
