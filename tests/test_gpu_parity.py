@@ -244,6 +244,12 @@ def test_nonstrict_flags_and_step_count_info(torch_cuda):
     assert info["timeout"].tolist() == [False, True] and done.tolist() == [True, True]
     assert info["step_count"].tolist() == [1, 1]
     assert env.positions.cpu().tolist() == [[6, 0]]
+    # out-of-range integers of any dtype are flagged, never wrapped into a legal move
+    env.reset()
+    for bad in (torch.tensor([-1, 256]), np.array([-3, 4]), torch.tensor([4, 255], dtype=torch.uint8)):
+        _, _, info = env.step(bad)
+        assert info["bad_action"].tolist() == [True, True]
+        assert env.positions.cpu().tolist() == [[0, 0]] and env.step_count.tolist() == [0, 0]
 
 
 def test_factory_levels_on_gpu(torch_cuda):

@@ -156,6 +156,24 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 
 // EXTRAS = false compiles the optional outputs (legality mask, reward, one-hot) out, so the
 // plain step / reset / encode path does not carry their registers and code.
+// Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only).  This
+// bijective remap gives the blocks that share an XCD one contiguous range of boards instead of
+// every 8th block:
+//   * output beyond the Infinity Cache: a fill kernel whose waves own 12 KiB chunks writes 708 MB
+//     at 5.4 TB/s in blockIdx order and at 5.9 TB/s XCD-contiguous (profiles/r01_membench_*):
+//     each XCD's L2 then drains one dense address range instead of 1/8 of every range;
+//   * k_large: a wave touches just 4..16 consecutive bytes of each SoA state row, so in blockIdx
+//     order every 128-B line of pos/tgt/blk would be read and partially written through all 8
+//     non-coherent L2s.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks) {
+#if TS_XCD_REMAP
+  const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#else
+  return bid;
+#endif
+}
+
 constexpr int kSmallBatch = 8;  // global loads in flight per lane in the any-T tile / target loops
 
 template <int S, int TFIX, bool EXTRAS>
@@ -169,7 +187,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int64_t n0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * kWave;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * kWave;
   if (n0 >= a.N) return;  // wave-uniform; no block-level barrier exists in this kernel
   const int64_t N = a.N;
   const int64_t n = n0 + lane;
@@ -517,20 +535,6 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
 // group share the board's tiles round-robin (tile t -> lane t mod G); masks are accumulated
 // with LDS atomic OR; group-wide AND/OR go through __ballot.
 // ------------------------------------------------------------------------------------------
-// Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only).  A wave
-// of k_large touches just 4..32 consecutive bytes of each SoA state row, so with the plain
-// blockIdx order every 128-B line of pos/tgt/blk would be read and partially written through
-// all 8 non-coherent L2s.  This bijective remap gives the blocks that share an XCD one contiguous
-// range of boards, so each line lives in one L2 and leaves it as one full-line write.
-__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks) {
-#if TS_XCD_REMAP
-  const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-#else
-  return bid;
-#endif
-}
-
 constexpr int kLoadBatch = 8;  // global loads in flight per lane in the tile / target loops
 
 struct LineMasks {

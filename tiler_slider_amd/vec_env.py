@@ -275,12 +275,16 @@ class VecTilerSliderEnv:
                 raise ValueError(f"actions must have shape ({self.num_envs},)")
             if actions.dtype == torch.uint8 and actions.device == self.device and actions.is_contiguous():
                 return actions
-            self._actions.copy_(actions.to(self.device, non_blocking=True).clamp(0, 255))
+            a = actions.to(self.device, non_blocking=True)
+            if a.dtype != torch.uint8:  # anything outside a byte becomes 255 = "bad action" for the kernel
+                a = torch.where((a < 0) | (a > 255), torch.full_like(a, 255), a)
+            self._actions.copy_(a)
             return self._actions
         if isinstance(actions, np.ndarray):
             if actions.dtype.kind not in "iu":
                 raise TypeError(f"actions array must hold integers, got {actions.dtype}")
-            return self._stage_actions(torch.from_numpy(np.ascontiguousarray(actions.clip(0, 255).astype(np.uint8))))
+            a = np.where((actions < 0) | (actions > 255), 255, actions).astype(np.uint8)
+            return self._stage_actions(torch.from_numpy(np.ascontiguousarray(a)))
         vals = []
         for a in actions:
             if not isinstance(a, Move):  # environment.py:116-117

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Calibration (development tool): streaming-store bandwidth of a trivial kernel for the bench's
-output sizes.  `build` here (ships with the snapshot), `run` on the GPU box."""
+"""Calibration (development tool): streaming-store bandwidth of a trivial kernel as a function of
+cache policy, bytes per wave, occupancy and block->address mapping.  `build` here (ships with the
+snapshot), `run` on the GPU box."""
 import ctypes as C
 import os
 import statistics
@@ -9,6 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SO = os.path.join(ROOT, "build", "membench.so")
+POLICY = {0: "plain", 1: "nt", 2: "sc1", 3: "sc0sc1"}
 
 if sys.argv[1] == "build":
     os.makedirs(os.path.dirname(SO), exist_ok=True)
@@ -18,26 +20,28 @@ if sys.argv[1] == "build":
 else:
     import torch
     L = C.CDLL(SO)
-    L.mb_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.mb_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     dev = torch.device("cuda", 0)
     st = torch.cuda.current_stream(dev).cuda_stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for mb in (708, 2100):
+    sizes = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [708]
+    for mb in sizes:
         nbytes = mb * 1000 * 1000 // 1024 * 1024
         buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        for nt in (0, 1):
-            for lds in (0, 12 * 1024):
-                for chunk in (1, 3, 12, 11, -3, -12, -11, -48):
-                    ts = []
-                    for r in range(5):
-                        for i in range(3):
-                            L.mb_fill(buf.data_ptr(), nbytes, 12345, nt, chunk, lds, st)
-                        e0.record()
-                        for i in range(20):
-                            L.mb_fill(buf.data_ptr(), nbytes, 12345, nt, chunk, lds, st)
-                        e1.record()
-                        torch.cuda.synchronize()
-                        ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-                    us = statistics.median(ts)
-                    print(f"{mb:4d} MB nonzero nt={nt} lds/block={lds // 1024:2d}K chunk={chunk:2d} KiB/wave: "
-                          f"{us:8.2f} us  {nbytes / us / 1e3:8.1f} GB/s", flush=True)
+        for policy in (0, 1, 2, 3):
+            for mode in (0, 1):
+                for lds in (0, 64 * 1024):
+                    for chunk in (1, 2, 12):
+                        ts = []
+                        for r in range(4):
+                            for i in range(3):
+                                L.mb_fill(buf.data_ptr(), nbytes, 12345, policy, chunk, lds, mode, st)
+                            e0.record()
+                            for i in range(20):
+                                L.mb_fill(buf.data_ptr(), nbytes, 12345, policy, chunk, lds, mode, st)
+                            e1.record()
+                            torch.cuda.synchronize()
+                            ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+                        us = statistics.median(ts)
+                        print(f"{mb:4d} MB {POLICY[policy]:6s} {'xcd-contig' if mode else 'blockIdx  '} lds/block={lds // 1024:2d}K "
+                              f"chunk={chunk:2d} KiB/wave: {us:8.2f} us  {nbytes / us / 1e3:8.1f} GB/s", flush=True)
