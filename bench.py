@@ -170,6 +170,19 @@ def main():
     total_boards = n * world
     value = total_boards * args.steps / wall
 
+    # the same loop through the public step() (argument staging + lazy info object, no sync):
+    # what a Python learner pays per call on top of the kernel
+    api = None
+    if world == 1:
+        k = min(args.steps, 200)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for i in range(k):
+            env.step(ring[i & 15])
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t1
+        api = {"value": n * k / dt, "unit": "env-steps/s", "us_per_call": dt / k * 1e6, "steps": k}
+
     gather = None
     if world > 1 and not args.no_gather:
         gather = time_gathers(env, ring, world, n, dist, torch, device, min(args.steps, 20))
@@ -197,6 +210,8 @@ def main():
                          "algorithmic_bytes_per_launch": bps * n,
                          "note": "working set < 256 MiB Infinity Cache at cfg1/cfg2: rate may exceed pure-HBM"},
         }
+        if api is not None:
+            line["python_step_api"] = api
         if gather is not None:
             line["allgather"] = gather
         if world == 1 and not args.no_cpu_baseline:
