@@ -171,3 +171,34 @@ def test_text_renderer_precedence():
     assert TextRender(env).render(show_info=False) == "A.a\n.X.\n..A"
     env.state = None
     assert "not initialized" in TextRender(env).render()
+
+
+def test_from_level_and_factory_construct_without_gpu():
+    """reference tests/test_environment.py:472-505 (from_level) and :369-401 (factory): building the
+    environment objects needs no device; only reset() does."""
+    from tiler_slider_amd import Level, TilerSliderEnv, TilerSliderEnvFactory
+    lvl = Level(size=4, blocked_locations=[(1, 0), (2, 3)], initial_locations=[(0, 3), (3, 2)],
+                target_locations=[(0, 0), (3, 0)], multiple_colors=True)
+    env = TilerSliderEnv.from_level(lvl, max_steps=50)
+    assert (env.size, env.max_steps, env.multi_color) == (4, 50, True)
+    assert env.blocked_locations == [(1, 0), (2, 3)] and env.initial_locations == [(0, 3), (3, 2)]
+    assert env.target_locations == [(0, 0), (3, 0)] and env.observation_shape == (4, 4, 3)
+    env = TilerSliderEnvFactory.create_simple_env(size=6, num_tiles=3, num_obstacles=4, seed=123)
+    assert env.size == 6 and env.multi_color is False and env.max_steps == 100
+    assert (len(env.blocked_locations), len(env.initial_locations), len(env.target_locations)) == (4, 3, 3)
+    again = TilerSliderEnvFactory.create_simple_env(size=6, num_tiles=3, num_obstacles=4, seed=123)
+    assert again.initial_locations == env.initial_locations and again.blocked_locations == env.blocked_locations
+    env = TilerSliderEnvFactory.create_from_string("a.X\n...\nX.A", multi_color=True)
+    assert env.size == 3 and env.multi_color is True
+    assert env.blocked_locations == [(0, 2), (2, 0)] and env.initial_locations == [(0, 0)]
+    assert env.target_locations == [(2, 2)]
+
+
+def test_bench_byte_accounting_matches_survey():
+    """212 B (cfg1), 322 B and 826 B (cfg2 without / with extensions), 2,840 B (cfg4)."""
+    import bench
+    assert bench.algorithmic_bytes_per_board_step(4, 2, False, False) == 212
+    assert bench.algorithmic_bytes_per_board_step(5, 2, False, False) == 322
+    assert bench.algorithmic_bytes_per_board_step(5, 2, True, True) == 826
+    assert bench.algorithmic_bytes_per_board_step(15, 32, False, False) == 2840
+    assert bench.host_cpu_share() >= 1

@@ -267,3 +267,45 @@ def test_edge_boards(make_env):
     _, done, info = env.step(Move.DOWN)  # both full rows drop to the bottom = the target set
     assert env.state.current_locations == [(8 + i // size, i % size) for i in range(n)]
     assert info["invalid_move"] is False and info["is_won"] is True and done is True
+
+
+def test_constructor_attributes_and_defaults(make_env):
+    """reference tests/test_environment.py:21-56."""
+    env = make_env(size=5, blocked_locations=[(1, 1)], initial_locations=[(0, 0)], target_locations=[(4, 4)],
+                   multi_color=False, max_steps=100)
+    assert env.size == 5 and env.max_steps == 100 and env.multi_color is False
+    assert env.observation_shape == (5, 5, 3)
+    env = make_env(size=3)
+    assert env.size == 3 and env.max_steps == 100
+    assert env.blocked_locations == [] and env.initial_locations == [] and env.target_locations == []
+    assert env.state is None and env.step_count == 0 and env.done is False
+
+
+def test_close_and_empty_board(make_env):
+    """reference tests/test_environment.py:351-363 (close) and tests/test_state.py:39-52 (a board
+    without tiles is won; a move on it changes nothing)."""
+    env = make_env(size=3, blocked_locations=[(1, 1)])
+    obs = env.reset()
+    assert obs.sum() == 1.0 and env.state.is_won() is True
+    _, done, info = env.step(Move.LEFT)
+    assert info["is_won"] is True and info["invalid_move"] is True and done is True
+    env.close()
+    assert env.state is None and env.get_info() == {"initialized": False} and env.get_valid_moves() == []
+
+
+def test_full_episode_until_timeout(make_env):
+    """reference tests/test_environment.py:511-546: play until done; counters and latch agree."""
+    env = make_env(size=4, blocked_locations=[(1, 1)], initial_locations=[(0, 0), (3, 3)],
+                   target_locations=[(1, 2), (2, 1)], multi_color=True, max_steps=7)
+    env.reset()
+    moves = [Move.RIGHT, Move.DOWN, Move.LEFT, Move.UP] * 3
+    steps = 0
+    for mv in moves:
+        _, done, info = env.step(mv)
+        steps += 1
+        assert info["step_count"] == steps - 1
+        if done:
+            break
+    assert steps == 7 and info.get("timeout") is True and env.done is True and env.step_count == 7
+    obs = env.reset()
+    assert env.done is False and env.step_count == 0 and obs[0, 0, 1] == 1.0 and obs[3, 3, 1] == 2.0

@@ -28,20 +28,17 @@ else:
     for mb in sizes:
         nbytes = mb * 1000 * 1000 // 1024 * 1024
         buf = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        for policy in (0, 1, 2, 3):
-            for mode in (0, 1):
-                for lds in (0, 64 * 1024):
-                    for chunk in (1, 2, 12):
-                        ts = []
-                        for r in range(4):
-                            for i in range(3):
-                                L.mb_fill(buf.data_ptr(), nbytes, 12345, policy, chunk, lds, mode, st)
-                            e0.record()
-                            for i in range(20):
-                                L.mb_fill(buf.data_ptr(), nbytes, 12345, policy, chunk, lds, mode, st)
-                            e1.record()
-                            torch.cuda.synchronize()
-                            ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-                        us = statistics.median(ts)
-                        print(f"{mb:4d} MB {POLICY[policy]:6s} {'xcd-contig' if mode else 'blockIdx  '} lds/block={lds // 1024:2d}K "
-                              f"chunk={chunk:2d} KiB/wave: {us:8.2f} us  {nbytes / us / 1e3:8.1f} GB/s", flush=True)
+        for seed, label in ((0, "zeros"), (1, "obs-like (1/8 nonzero)"), (12345, "dense nonzero")):
+            for chunk in (1, 12):
+                ts = []
+                for r in range(5):
+                    for i in range(3):
+                        L.mb_fill(buf.data_ptr(), nbytes, seed, 0, chunk, 0, 1, st)
+                    e0.record()
+                    for i in range(20):
+                        L.mb_fill(buf.data_ptr(), nbytes, seed, 0, chunk, 0, 1, st)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+                us = statistics.median(ts)
+                print(f"{mb:4d} MB plain xcd-contig chunk={chunk:2d} KiB/wave data={label}: {us:8.2f} us  {nbytes / us / 1e3:8.1f} GB/s", flush=True)
