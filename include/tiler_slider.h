@@ -20,8 +20,9 @@
  *
  * Device data layout (struct-of-arrays, board index fastest; N = n_boards,
  * S = size, C = S*S, cell id p = r*S + c with row 0 at the top):
- *    pos, init  uint8  [n_tiles  ][N]   cell id of tile t of board n
- *    tgt        uint8  [n_targets][N]   cell id of target j of board n
+ *    pos, init  cell_t [n_tiles  ][N]   cell id of tile t of board n
+ *    tgt        cell_t [n_targets][N]   cell id of target j of board n
+ *               cell_t = uint8 for S <= 16 (C <= 256), uint16 for S = 17..32: ts_cell_bytes(S)
  *    blk        uint32 [W][N]           W = ts_blk_words(S); bit (p & 31) of word
  *                                       (p >> 5) set <=> cell p is an obstacle
  *    step_count int32  [N]
@@ -43,7 +44,7 @@ extern "C" {
 #endif
 
 #define TS_ABI_VERSION 1
-#define TS_MAX_SIZE 16   /* cell ids are uint8: C = S*S <= 256 */
+#define TS_MAX_SIZE 32   /* cell ids: uint8 up to 16x16, uint16 up to 32x32 (ts_cell_bytes) */
 #define TS_MAX_TILES 255 /* observation stores tile index + 1 in one byte */
 
 /* ref: explainrl/environment/state.py:29-35 (GameState.Move values) */
@@ -90,9 +91,9 @@ typedef struct ts_dims {
 } ts_dims;
 
 typedef struct ts_state {
-  uint8_t *pos;        /* [T][N]  current_locations */
-  const uint8_t *init; /* [T][N]  initial_locations (level) */
-  const uint8_t *tgt;  /* [Tt][N] target_locations  (level) */
+  void *pos;           /* cell_t [T][N]  current_locations */
+  const void *init;    /* cell_t [T][N]  initial_locations (level) */
+  const void *tgt;     /* cell_t [Tt][N] target_locations  (level) */
   const uint32_t *blk; /* [W][N]  is_blocked bitmask (level) */
   int32_t *step_count; /* [N] */
   uint8_t *done;       /* [N] */
@@ -114,6 +115,8 @@ const char *ts_status_string(int32_t status);
 int32_t ts_last_hip_error(void);
 /* W: uint32 words of the obstacle bitmask for an S x S board = ceil(S*S/32). */
 int32_t ts_blk_words(int32_t size);
+/* sizeof(cell_t) of pos / init / tgt for an S x S board: 1 (S <= 16) or 2 (S <= 32); 0 if invalid. */
+int32_t ts_cell_bytes(int32_t size);
 /* Ch of the one-hot encoding: 1 + T + Tt if multi_color else 3. */
 int32_t ts_onehot_channels(const ts_dims *dims);
 /* Checks dims against the limits; TS_OK or the error ts_step would return. */

@@ -81,6 +81,11 @@ def blk_words(size):
     return (size * size + 31) // 32
 
 
+def cell_dtype(size):
+    """Element type of pos / init / tgt: uint8 up to 16x16, uint16 up to 32x32."""
+    return np.uint8 if size <= 16 else np.uint16
+
+
 # --- single-board restatements (reference data model) --------------------------------------
 def _grid(size, blocked_locations):
     g = np.zeros(size * size, np.uint8)
@@ -132,8 +137,8 @@ def pack_levels(size, levels):
     T = len(levels[0][1]) if N else 0
     Tt = len(levels[0][2]) if N else 0
     blk = np.zeros((blk_words(size), N), np.uint32)
-    init = np.zeros((T, N), np.uint8)
-    tgt = np.zeros((Tt, N), np.uint8)
+    init = np.zeros((T, N), cell_dtype(size))
+    tgt = np.zeros((Tt, N), cell_dtype(size))
     for n, (b, i, t) in enumerate(levels):
         assert len(i) == T and len(t) == Tt
         for r, c in b:
@@ -152,8 +157,8 @@ class OracleBatch:
     def __init__(self, size, multi_color, max_steps, blk, init, tgt):
         self.size, self.multi_color, self.max_steps = int(size), bool(multi_color), int(max_steps)
         self.blk = np.ascontiguousarray(blk, np.uint32)
-        self.init = np.ascontiguousarray(init, np.uint8)
-        self.tgt = np.ascontiguousarray(tgt, np.uint8)
+        self.init = np.ascontiguousarray(init, cell_dtype(size))
+        self.tgt = np.ascontiguousarray(tgt, cell_dtype(size))
         self.n_tiles, self.n_targets = self.init.shape[0], self.tgt.shape[0]
         self.n = self.blk.shape[1]
         assert self.blk.shape[0] == blk_words(size)
@@ -227,8 +232,8 @@ class OracleBatch:
 def generate(size, n_tiles, n_targets, n_obstacles, n_boards, seed, board_offset=0):
     """Twin of ts_generate: returns (blk[W,N], init[T,N], tgt[Tt,N])."""
     blk = np.zeros((blk_words(size), n_boards), np.uint32)
-    init = np.zeros((n_tiles, n_boards), np.uint8)
-    tgt = np.zeros((n_targets, n_boards), np.uint8)
+    init = np.zeros((n_tiles, n_boards), cell_dtype(size))
+    tgt = np.zeros((n_targets, n_boards), cell_dtype(size))
     dims = Dims(n_boards, size, n_tiles, n_targets, 0, 1, 0)
     st = State(None, _p(init), _p(tgt), _p(blk), None, None)
     rc = lib().tso_generate(C.byref(dims), C.byref(st), seed, board_offset, n_obstacles)

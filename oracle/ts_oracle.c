@@ -200,28 +200,39 @@ typedef struct board {
   int32_t trows[TS_MAX_TILES + 1], tcols[TS_MAX_TILES + 1];
 } board;
 
+/* cell ids are uint8 up to 16x16 and uint16 up to 32x32 (include/tiler_slider.h) */
+static inline int cell_get(const ts_dims *d, const void *a, int64_t i) {
+  return d->size <= 16 ? ((const uint8_t *)a)[i] : ((const uint16_t *)a)[i];
+}
+static inline void cell_set(const ts_dims *d, void *a, int64_t i, int v) {
+  if (d->size <= 16)
+    ((uint8_t *)a)[i] = (uint8_t)v;
+  else
+    ((uint16_t *)a)[i] = (uint16_t)v;
+}
+
 static void load_level(const ts_dims *d, const ts_state *st, int64_t n, board *b) {
   const int S = d->size, C = S * S;
   const int64_t N = d->n_boards;
   for (int p = 0; p < C; ++p) b->blocked[p] = (uint8_t)((st->blk[(int64_t)(p >> 5) * N + n] >> (p & 31)) & 1u);
   for (int j = 0; j < d->n_targets; ++j) {
-    int p = st->tgt[(int64_t)j * N + n];
+    int p = cell_get(d, st->tgt, (int64_t)j * N + n);
     b->trows[j] = p / S;
     b->tcols[j] = p % S;
   }
 }
 
-static void load_tiles(const ts_dims *d, const uint8_t *src, int64_t n, board *b) {
+static void load_tiles(const ts_dims *d, const void *src, int64_t n, board *b) {
   const int S = d->size;
   for (int i = 0; i < d->n_tiles; ++i) {
-    int p = src[(int64_t)i * d->n_boards + n];
+    int p = cell_get(d, src, (int64_t)i * d->n_boards + n);
     b->rows[i] = p / S;
     b->cols[i] = p % S;
   }
 }
 
-static void store_tiles(const ts_dims *d, uint8_t *dst, int64_t n, const board *b) {
-  for (int i = 0; i < d->n_tiles; ++i) dst[(int64_t)i * d->n_boards + n] = (uint8_t)(b->rows[i] * d->size + b->cols[i]);
+static void store_tiles(const ts_dims *d, void *dst, int64_t n, const board *b) {
+  for (int i = 0; i < d->n_tiles; ++i) cell_set(d, dst, (int64_t)i * d->n_boards + n, b->rows[i] * d->size + b->cols[i]);
 }
 
 static void encode_board(const ts_dims *d, const board *b, float *obs_n) {
@@ -449,7 +460,7 @@ int32_t tso_generate(const ts_dims *d, const ts_state *st, uint64_t seed, int64_
   const int64_t N = d->n_boards;
   if (K < 0 || K + T + Tt > C) return TS_ERR_DIMS;
   if (!st || !st->blk || (T && !st->init) || (Tt && !st->tgt)) return TS_ERR_NULL;
-  uint8_t *init = (uint8_t *)st->init, *tgt = (uint8_t *)st->tgt;
+  void *init = (void *)st->init, *tgt = (void *)st->tgt;
   uint32_t *blk = (uint32_t *)st->blk;
 #pragma omp parallel for schedule(static) num_threads(tso_num_threads())
   for (int64_t n = 0; n < N; ++n) {
@@ -475,9 +486,9 @@ int32_t tso_generate(const ts_dims *d, const ts_state *st, uint64_t seed, int64_
       if (got < K)
         words[cell >> 5] |= 1u << (cell & 31);
       else if (got < K + T)
-        init[(int64_t)(got - K) * N + n] = (uint8_t)cell;
+        cell_set(d, init, (int64_t)(got - K) * N + n, cell);
       else
-        tgt[(int64_t)(got - K - T) * N + n] = (uint8_t)cell;
+        cell_set(d, tgt, (int64_t)(got - K - T) * N + n, cell);
       ++got;
     }
     for (int w = 0; w < W; ++w) blk[(int64_t)w * N + n] = words[w];

@@ -132,6 +132,12 @@ GROUPS = [
     ("s15_t32_sc", 15, 32, 32, 24, False, 8, 24, "random"),
     ("s16_t40_mc", 16, 40, 40, 30, True, 8, 16, "random"),
     ("s16_t255_sc", 16, 255, 255, 0, False, 2, 8, "random"),    # maximum tile count, nearly full board
+    # boards above 16x16: 16-bit cell ids
+    ("s17_t3_mc", 17, 3, 3, 20, True, 8, 16, "reachable"),
+    ("s20_t1_sc", 20, 1, 1, 1, False, 6, 16, "reachable"),      # test_state.py:614-625 shape (20x20)
+    ("s24_t30_mc", 24, 30, 30, 60, True, 4, 16, "random"),
+    ("s32_t64_sc", 32, 64, 64, 100, False, 3, 12, "random"),
+    ("s32_t255_mc", 32, 255, 255, 200, True, 2, 8, "random"),   # largest board, maximum tile count
 ]
 
 

@@ -27,8 +27,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, sym), f"{sym} declared in include/tiler_slider.h but not exported"
     assert set(declared) == set(_cabi.EXPORTS)
     assert L.ts_abi_version() == 1
-    assert _cabi.limits() == (16, 255)
-    assert [L.ts_blk_words(s) for s in (1, 4, 5, 6, 8, 15, 16)] == [1, 1, 1, 2, 2, 8, 8]
+    assert _cabi.limits() == (32, 255)
+    assert [L.ts_blk_words(s) for s in (1, 4, 5, 6, 8, 15, 16, 20, 32)] == [1, 1, 1, 2, 2, 8, 8, 13, 32]
+    assert [L.ts_cell_bytes(s) for s in (0, 1, 16, 17, 32, 33)] == [0, 1, 1, 2, 2, 0]
     assert L.ts_status_string(0) == b"ok" and b"NULL" in L.ts_status_string(-1)
 
 
@@ -40,8 +41,8 @@ def test_argument_validation_precedes_any_launch():
     assert L.ts_onehot_channels(C.byref(ok)) == 5
     assert L.ts_onehot_channels(C.byref(_cabi.Dims(8, 4, 2, 2, 0, 100, 0))) == 3
     for bad, want in ((_cabi.Dims(-1, 4, 2, 2, 0, 100, 0), _cabi.ERR_DIMS), (_cabi.Dims(8, 0, 2, 2, 0, 100, 0), _cabi.ERR_DIMS),
-                      (_cabi.Dims(8, 17, 2, 2, 0, 100, 0), _cabi.ERR_LIMIT), (_cabi.Dims(8, 4, 17, 2, 0, 100, 0), _cabi.ERR_DIMS),
-                      (_cabi.Dims(8, 16, 256, 2, 0, 100, 0), _cabi.ERR_LIMIT), (_cabi.Dims(8, 4, 2, 2, 2, 100, 0), _cabi.ERR_DIMS),
+                      (_cabi.Dims(8, 33, 2, 2, 0, 100, 0), _cabi.ERR_LIMIT), (_cabi.Dims(8, 4, 17, 2, 0, 100, 0), _cabi.ERR_DIMS),
+                      (_cabi.Dims(8, 32, 256, 2, 0, 100, 0), _cabi.ERR_LIMIT), (_cabi.Dims(8, 4, 2, 2, 2, 100, 0), _cabi.ERR_DIMS),
                       (_cabi.Dims(8, 4, 2, 2, 0, 0, 0), _cabi.ERR_DIMS), (_cabi.Dims(8, 4, 2, 2, 0, 100, 1), _cabi.ERR_DIMS)):
         assert L.ts_check_dims(C.byref(bad)) == want
     st, out = _cabi.State(), _cabi.StepOut()
@@ -153,8 +154,12 @@ def test_pack_levels_layout_and_validation():
         pack_levels(3, [[]], [[(3, 0)]], [[(1, 1)]])
     with pytest.raises(ValueError, match="same number"):
         pack_levels(3, [[], []], [[(0, 0)], [(0, 0), (1, 1)]], [[(1, 1)], [(1, 1)]])
-    with pytest.raises(ValueError, match="size must be"):  # reference test_state.py:614-625 builds 20x20
-        pack_levels(20, [[(10, 10)]], [[(0, 0)]], [[(19, 19)]])
+    with pytest.raises(ValueError, match="size must be"):
+        pack_levels(33, [[(10, 10)]], [[(0, 0)]], [[(19, 19)]])
+    # above 16x16 the cell ids are 16-bit (reference tests/test_state.py:614-625 builds 20x20)
+    blk, init, tgt = pack_levels(20, [[(10, 10)]], [[(0, 0)]], [[(19, 19)]])
+    assert init.dtype == np.uint16 and tgt.dtype == np.uint16 and blk.shape == (13, 1)
+    assert tgt[0, 0] == 399 and blk[210 >> 5, 0] == 1 << (210 & 31)
 
 
 def test_text_renderer_precedence():

@@ -51,7 +51,7 @@ def test_hip_replays_reference_golden(torch_cuda, name):
         np.testing.assert_array_equal(env.encode().cpu().numpy(), g["obs"][:, l].astype(np.float32))
 
 
-@pytest.mark.parametrize("name", ["s3_t1", "s4_t2_mc", "s5_t2_sc", "s8_t20_mc", "s15_t32_mc"])
+@pytest.mark.parametrize("name", ["s3_t1", "s4_t2_mc", "s5_t2_sc", "s8_t20_mc", "s15_t32_mc", "s20_t1_sc", "s32_t64_sc"])
 def test_gamestate_adapter_matches_reference_golden(torch_cuda, name):
     """The one-board GameState adapter (move / is_won / get_state_array / move_to / copy)."""
     from tiler_slider_amd import GameState
@@ -85,6 +85,9 @@ RANDOM_SHAPES = [
     (8, 30, 10, False, 259, 40), (8, 60, 2, True, 131, 40),
     (9, 4, 9, True, 1023, 12), (10, 20, 0, False, 515, 40), (12, 16, 20, True, 258, 40), (13, 1, 30, False, 130, 9),
     (15, 32, 24, True, 1030, 40), (15, 32, 24, False, 259, 40), (16, 40, 30, True, 66, 40), (16, 255, 0, False, 9, 40),
+    # above 16x16: uint16 cell ids, 32-bit line masks
+    (17, 3, 20, True, 257, 12), (20, 1, 1, False, 130, 9), (24, 30, 60, True, 67, 40), (27, 100, 90, False, 18, 40),
+    (32, 64, 100, False, 35, 40), (32, 255, 200, True, 10, 40),
 ]
 
 
@@ -137,7 +140,8 @@ def test_mismatched_tile_and_target_counts(torch_cuda, oracle):
     """len(tiles) != len(targets) (reachable through create_from_string, environment.py:236-288)."""
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv
-    for S, T, Tt, mc in ((4, 2, 3, True), (4, 3, 1, False), (5, 0, 2, False), (12, 5, 9, True), (12, 9, 5, False)):
+    for S, T, Tt, mc in ((4, 2, 3, True), (4, 3, 1, False), (5, 0, 2, False), (12, 5, 9, True), (12, 9, 5, False),
+                         (21, 4, 7, True), (21, 7, 4, False)):
         N = 300
         blk, init, _ = oracle.generate(S, T, T, 3, N, seed=5)
         _, _, tgt = oracle.generate(S, Tt, Tt, 0, N, seed=6)
@@ -158,13 +162,14 @@ def test_mismatched_tile_and_target_counts(torch_cuda, oracle):
 def test_generator_and_actions_match_twin(torch_cuda, oracle):
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv
-    for S, T, K in ((3, 1, 0), (4, 2, 2), (5, 2, 3), (8, 20, 10), (15, 32, 24), (16, 100, 50)):
+    for S, T, K in ((3, 1, 0), (4, 2, 2), (5, 2, 3), (8, 20, 10), (15, 32, 24), (16, 100, 50), (20, 30, 40),
+                    (32, 255, 300)):
         N, off = 3001, 12345
         env = VecTilerSliderEnv.random(N, size=S, num_tiles=T, num_obstacles=K, seed=0x715311DE, board_offset=off)
         blk, init, tgt = oracle.generate(S, T, T, K, N, seed=0x715311DE, board_offset=off)
         np.testing.assert_array_equal(env._blk.cpu().numpy().view(np.uint32), blk)
-        np.testing.assert_array_equal(env._init.cpu().numpy(), init)
-        np.testing.assert_array_equal(env._tgt.cpu().numpy(), tgt)
+        np.testing.assert_array_equal(env._init.cpu().numpy().astype(np.int64), init.astype(np.int64))
+        np.testing.assert_array_equal(env._tgt.cpu().numpy().astype(np.int64), tgt.astype(np.int64))
         # level invariants of the reference factory (tests/test_environment.py:403-417): no overlaps
         cells = np.concatenate([init, tgt]).astype(np.int64)
         for n in range(0, N, 97):

@@ -246,9 +246,8 @@ def test_observation_channels_multi_color(make_env):
 
 
 def test_edge_boards(make_env):
-    """reference tests/test_state.py:587-642: 1x1 board, a tile walled in by obstacles, 20 tiles on
-    10x10.  (The 20x20 construction-only case is above this build's TS_MAX_SIZE = 16 and is
-    covered by test_limits in test_host_logic.py.)"""
+    """reference tests/test_state.py:587-642: 1x1 board, a tile walled in by obstacles, the 20x20
+    board, 20 tiles on 10x10."""
     env = make_env(size=1, initial_locations=[(0, 0)], target_locations=[(0, 0)])
     env.reset()
     assert env.state.is_won() is True
@@ -259,6 +258,14 @@ def test_edge_boards(make_env):
     env.reset()
     env.step(Move.RIGHT)
     assert env.state.current_locations == [(0, 0)]
+    env = make_env(size=20, blocked_locations=[(10, 10)], initial_locations=[(0, 0)], target_locations=[(19, 19)])
+    obs = env.reset()
+    assert env.size == 20 and env.state.is_blocked.shape == (20, 20) and obs.shape == (20, 20, 3)
+    assert bool(env.state.is_blocked[10, 10]) and obs[10, 10, 0] == 1.0 and obs[19, 19, 2] == 1.0
+    env.step(Move.DOWN)
+    assert env.state.current_locations == [(19, 0)]
+    _, done, info = env.step(Move.RIGHT)
+    assert env.state.current_locations == [(19, 19)] and done is True and info["is_won"] is True
     size, n = 10, 20
     init = [(i // size, i % size) for i in range(n)]
     tgt = [(size - 1 - i // size, size - 1 - i % size) for i in range(n)]

@@ -21,7 +21,7 @@ FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
 MODE_STRICT, MODE_AUTORESET = 0, 1
 
-EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words",
+EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
            "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions")
 
@@ -99,6 +99,8 @@ def lib():
     L.ts_last_hip_error.restype = C.c_int32
     L.ts_blk_words.argtypes = [C.c_int32]
     L.ts_blk_words.restype = C.c_int32
+    L.ts_cell_bytes.argtypes = [C.c_int32]
+    L.ts_cell_bytes.restype = C.c_int32
     L.ts_onehot_channels.argtypes = [DP]
     L.ts_onehot_channels.restype = C.c_int32
     L.ts_check_dims.argtypes = [DP]

@@ -527,26 +527,32 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_large: S in 9..16.  G = 2^gshift lanes cooperate on one board (64/G boards per wave); the
-// host picks G so that a wave's LDS carve stays near 16 KiB (G = 4 at 15x15 with 32 tiles).
-// Obstacles, tiles and targets are kept as line masks in LDS: word i of a LineMasks array
-// holds row i's cells in bits 0..15 and column i's cells in bits 16..31; a tile's new index
-// along its lane comes from ts::slide_line on the lane's obstacle and tile masks.  Lanes of a
-// group share the board's tiles round-robin (tile t -> lane t mod G); masks are accumulated
-// with LDS atomic OR; group-wide AND/OR go through __ballot.
+// k_large<WIDE>: S in 9..16 (WIDE = false, uint8 cell ids) and 17..32 (WIDE = true, uint16 cell
+// ids).  G = 2^gshift lanes cooperate on one board (64/G boards per wave); the host picks G.
+// Obstacles, tiles and targets are kept as line masks in LDS (one 32-bit word per row / per
+// column, bit i = i-th cell along the line); a tile's new index along its lane comes from
+// ts::slide_line on the lane's obstacle and tile masks.  Lanes of a group share the board's
+// tiles round-robin (tile t -> lane t mod G); masks are accumulated with LDS atomic OR;
+// group-wide AND/OR go through __ballot.
 // ------------------------------------------------------------------------------------------
 constexpr int kLoadBatch = 8;  // global loads in flight per lane in the tile / target loops
 
+template <int MAXS>
 struct LineMasks {
-  uint32_t B[16];  // obstacles
-  uint32_t O[16];  // tiles before the move
-  uint32_t Nw[16]; // tiles after the move
-  uint32_t Tm[16]; // targets
+  uint32_t Br[MAXS], Bc[MAXS];  // obstacles of row r / of column c
+  uint32_t O[MAXS];             // tiles before the move, along the move's lanes only (columns for
+                                // a vertical move, rows for a horizontal one)
+  uint32_t Nr[MAXS], Nc[MAXS];  // tiles after the move, rows / columns
+  uint32_t Tm[MAXS];            // targets, rows
 };
 
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const int gshift, const uint32_t invS) {
-  // x / S for x < 256 without the ~25-instruction runtime division: invS = ceil(65536 / S) makes
-  // (x * invS) >> 16 exact for S <= 16 (the error term x / 65536 stays below 1/S).
+  using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
+  using Masks = LineMasks<WIDE ? 32 : 16>;
+  constexpr int kWords = WIDE ? 32 : 8;  // packed obstacle words of one board
+  // x / S for x < S*S without the ~25-instruction runtime division: invS = ceil(65536 / S) makes
+  // (x * invS) >> 16 exact for S <= 32 (checked exhaustively; the error x / 65536 stays below 1/S).
   auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
   auto cell_of = [&](int r, int c) -> int { return (int)__umul24((uint32_t)r, (uint32_t)S) + c; };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -565,15 +571,18 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
   const int C = S * S, W = (C + 31) >> 5;
   const int T = a.T, Tt = a.Tt;
   const bool mc = a.mc != 0;
-  const uint32_t rowmask = (1u << S) - 1;
+  const uint32_t rowmask = S >= 32 ? 0xffffffffu : (1u << S) - 1;
   const uint64_t gmask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (g << gshift);
 
   unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;  // [BPW][3C] bytes, flat
   unsigned char *stage = img + a.lds_stage_off;
-  LineMasks *L0 = reinterpret_cast<LineMasks *>(stage);
-  LineMasks *L = L0 + g;
-  unsigned char *cells0 = stage + (size_t)BPW * sizeof(LineMasks);
-  unsigned char *cells = cells0 + (size_t)g * (T + Tt);  // [T] tile cells, then [Tt] target cells
+  Masks *L0 = reinterpret_cast<Masks *>(stage);
+  Masks *L = L0 + g;
+  cell_t *cells0 = reinterpret_cast<cell_t *>(stage + (size_t)BPW * sizeof(Masks));
+  cell_t *cells = cells0 + (size_t)g * (T + Tt);  // [T] tile cells, then [Tt] target cells
+  const cell_t *g_pos = reinterpret_cast<const cell_t *>(a.pos);
+  const cell_t *g_init = reinterpret_cast<const cell_t *>(a.init);
+  const cell_t *g_tgt = reinterpret_cast<const cell_t *>(a.tgt);
 
   // ---- per-board scalars (the group's lanes load the same address: one request) ----
   uint32_t action = 0, done_in = 0;
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
 
   // Which masks this launch needs (all wave-uniform except `vert`, which is per board):
   //   column halves        : vertical slides, and the legality mask (all four directions)
-  //   post-move tiles  Nw  : set-equality win test (rows), legality mask (rows + columns)
+  //   post-move tiles Nr/Nc: set-equality win test (rows), legality mask (rows + columns)
   //   targets          Tm  : set-equality win test
   const bool need_new = !mc || a.valid != nullptr;
   const bool need_cols = a.valid != nullptr || (kind == 0 && vert);
@@ -611,20 +620,20 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
   // ---- clear the line masks; park the packed obstacle words in the (not yet used) image ----
   {
     uint4 *z = reinterpret_cast<uint4 *>(L0);
-    const int n16 = BPW * (int)sizeof(LineMasks) / 16;
+    const int n16 = BPW * (int)sizeof(Masks) / 16;
     for (int i = lane; i < n16; i += kWave) z[i] = make_uint4(0, 0, 0, 0);
   }
-  uint32_t *words = reinterpret_cast<uint32_t *>(img) + g * 8;
-  for (int w = j; w < 8; w += G) words[w] = (live && w < W) ? a.blk[(int64_t)w * N + n] : 0u;
+  uint32_t *words = reinterpret_cast<uint32_t *>(img) + g * kWords;
+  for (int w = j; w < kWords; w += G) words[w] = (live && w < W) ? a.blk[(int64_t)w * N + n] : 0u;
   wave_sync();
   for (int r = j; r < S; r += G) {
     const int bit0 = r * S, w0 = bit0 >> 5, sh = bit0 & 31;
     uint64_t two = (uint64_t)words[w0];
-    if (w0 + 1 < 8) two |= (uint64_t)words[w0 + 1] << 32;
+    if (w0 + 1 < kWords) two |= (uint64_t)words[w0 + 1] << 32;
     const uint32_t rb = (uint32_t)(two >> sh) & rowmask;
-    if (rb) atomicOr(&L->B[r], rb);
+    L->Br[r] = rb;  // row r belongs to this lane alone
     if (need_cols)
-      for (uint32_t m = rb; m; m &= m - 1) atomicOr(&L->B[ts::lsb(m)], 1u << (16 + r));
+      for (uint32_t m = rb; m; m &= m - 1) atomicOr(&L->Bc[ts::lsb(m)], 1u << r);
   }
 
   // ---- pass 1: pre-move cells into LDS, line occupancy by atomic OR ----
@@ -644,13 +653,13 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
 #pragma unroll
     for (int u = 0; u < kLoadBatch; ++u) {
       const int t = t0 + u * G;
-      v[u] = (live && t < T && !all_reset) ? (int)a.pos[off0 + u * group_stride] : 0;
+      v[u] = (live && t < T && !all_reset) ? (int)g_pos[off0 + u * group_stride] : 0;
     }
     if (kind == 2 && live) {
 #pragma unroll
       for (int u = 0; u < kLoadBatch; ++u) {
         const int t = t0 + u * G;
-        if (t < T) v[u] = (int)a.init[off0 + u * group_stride];
+        if (t < T) v[u] = (int)g_init[off0 + u * group_stride];
       }
     }
 #pragma unroll
@@ -658,11 +667,11 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
       const int t = t0 + u * G;
       if (t < T) {
         const int pt = min(v[u], C - 1);
-        cells[t] = (unsigned char)pt;
+        cells[t] = (cell_t)pt;
         if (kind == 0) {  // occupancy of the lanes the move runs along
           const int r = div_s(pt), c = pt - (int)__umul24((uint32_t)r, (uint32_t)S);
           if (vert)
-            atomicOr(&L->O[c], 1u << (16 + r));
+            atomicOr(&L->O[c], 1u << r);
           else
             atomicOr(&L->O[r], 1u << c);
         }
@@ -675,14 +684,14 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
 #pragma unroll
     for (int u = 0; u < kLoadBatch; ++u) {
       const int t = t0 + u * G;
-      v[u] = (live && t < Tt) ? (int)a.tgt[off0 + u * group_stride] : 0;
+      v[u] = (live && t < Tt) ? (int)g_tgt[off0 + u * group_stride] : 0;
     }
 #pragma unroll
     for (int u = 0; u < kLoadBatch; ++u) {
       const int t = t0 + u * G;
       if (t < Tt) {
         const int tj = min(v[u], C - 1);
-        cells[T + t] = (unsigned char)tj;
+        cells[T + t] = (cell_t)tj;
         if (!mc) {
           const int r = div_s(tj), c = tj - (int)__umul24((uint32_t)r, (uint32_t)S);
           atomicOr(&L->Tm[r], 1u << c);
@@ -694,30 +703,30 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
 
   // ---- pass 2: slide (state.py:120-170) ----
   bool same = true, ordered = true;
-  uint8_t *pos_out = a.pos + lane_off;
+  cell_t *pos_out = reinterpret_cast<cell_t *>(a.pos) + lane_off;
   for (int t = j; t < T; t += G, pos_out += group_stride) {
     const int pt = cells[t];
     int r = div_s(pt), c = pt - (int)__umul24((uint32_t)r, (uint32_t)S);
     if (kind == 0) {
       if (vert)
-        r = ts::slide_line(r, L->B[c] >> 16, L->O[c] >> 16, S, neg);
+        r = ts::slide_line(r, L->Bc[c], L->O[c], S, neg);
       else
-        c = ts::slide_line(c, L->B[r] & 0xffffu, L->O[r] & 0xffffu, S, neg);
+        c = ts::slide_line(c, L->Br[r], L->O[r], S, neg);
     }
     const int qt = cell_of(r, c);
     same &= qt == pt;
     if (t < Tt) ordered &= qt == (int)cells[T + t];
     if (need_new) {
-      atomicOr(&L->Nw[r], 1u << c);
-      if (a.valid) atomicOr(&L->Nw[c], 1u << (16 + r));
+      atomicOr(&L->Nr[r], 1u << c);
+      if (a.valid) atomicOr(&L->Nc[c], 1u << r);
     }
-    if (live && kind != 1) *pos_out = (uint8_t)qt;
-    cells[t] = (unsigned char)qt;  // only this lane reads cells[t] before the next wave_sync
+    if (live && kind != 1) *pos_out = (cell_t)qt;
+    cells[t] = (cell_t)qt;  // only this lane reads cells[t] before the next wave_sync
   }
   wave_sync();
   bool rows_equal = true;
   if (!mc)
-    for (int r = j; r < S; r += G) rows_equal &= ((L->Nw[r] ^ L->Tm[r]) & 0xffffu) == 0;
+    for (int r = j; r < S; r += G) rows_equal &= L->Nr[r] == L->Tm[r];
   const bool all_same = (__ballot(same) & gmask) == gmask;
   const bool all_ordered = (T == Tt) && ((__ballot(ordered) & gmask) == gmask);
   const bool all_rows = (__ballot(rows_equal) & gmask) == gmask;
@@ -752,8 +761,8 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
       for (int t = j; t < T; t += G) {
         const int qt = cells[t];
         const int r = div_s(qt), c = qt - (int)__umul24((uint32_t)r, (uint32_t)S);
-        const int x = d < 2 ? ts::slide_line(r, L->B[c] >> 16, L->Nw[c] >> 16, S, (d & 1) == 0)
-                            : ts::slide_line(c, L->B[r] & 0xffffu, L->Nw[r] & 0xffffu, S, (d & 1) == 0);
+        const int x = d < 2 ? ts::slide_line(r, L->Bc[c], L->Nc[c], S, (d & 1) == 0)
+                            : ts::slide_line(c, L->Br[r], L->Nr[r], S, (d & 1) == 0);
         moved |= x != (d < 2 ? r : c);
       }
       vm |= ((__ballot(moved) & gmask) != 0 ? 1u : 0u) << d;
@@ -799,7 +808,7 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
     unsigned char *my = img + g * (3 * C);
     if (live) {
       for (int r = j; r < S; r += G)
-        for (uint32_t m = L->B[r] & 0xffffu; m; m &= m - 1) my[3 * cell_of(r, ts::lsb(m))] = 1;
+        for (uint32_t m = L->Br[r]; m; m &= m - 1) my[3 * cell_of(r, ts::lsb(m))] = 1;
       for (int t = j; t < T; t += G) my[3 * cells[t] + 1] = (unsigned char)(mc ? t + 1 : 1);
       for (int t = j; t < Tt; t += G) my[3 * cells[T + t] + 2] = (unsigned char)(mc ? t + 1 : 1);
     }
@@ -834,11 +843,11 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
       const int cr = div_s(cell), cc = cell - cell_of(cr, 0);
       uint32_t bit;
       if (plane == 0) {
-        bit = (L0[b].B[cr] >> cc) & 1u;
+        bit = (L0[b].Br[cr] >> cc) & 1u;
       } else if (mc) {
         bit = (int)cells0[(size_t)b * (T + Tt) + plane - 1] == cell;  // tiles then targets, contiguous
       } else {
-        bit = ((plane == 1 ? L0[b].Nw[cr] : L0[b].Tm[cr]) >> cc) & 1u;
+        bit = ((plane == 1 ? L0[b].Nr[cr] : L0[b].Tm[cr]) >> cc) & 1u;
       }
       return bit ? 1.0f : 0.0f;
     };
@@ -876,13 +885,16 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
 // ------------------------------------------------------------------------------------------
 // Synthetic inputs
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_generate(uint32_t *blk, uint8_t *init, uint8_t *tgt, int64_t N, int S, int T,
-                                                   int Tt, int K, uint64_t seed, int64_t board_offset) {
+template <typename cell_t>
+__global__ __launch_bounds__(256) void k_generate(uint32_t *blk, cell_t *init, cell_t *tgt, int64_t N, int S, int T, int Tt,
+                                                   int K, uint64_t seed, int64_t board_offset) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const int C = S * S, W = (C + 31) >> 5;
   const uint64_t key = ts::mix64(seed ^ ((uint64_t)(board_offset + n) * ts::kBoardMul));
-  uint64_t taken[4] = {0, 0, 0, 0}, blocked[4] = {0, 0, 0, 0};
+  constexpr int kMaskWords = sizeof(cell_t) == 1 ? 8 : 32;  // 256 / 1024 cells
+  uint32_t taken[kMaskWords], blocked[kMaskWords];          // runtime-indexed: lives in scratch, not hot
+  for (int w = 0; w < kMaskWords; ++w) taken[w] = blocked[w] = 0;
   const int need = K + T + Tt;
   uint64_t draw = 0;
   for (int got = 0; got < need;) {
@@ -891,28 +903,21 @@ __global__ __launch_bounds__(256) void k_generate(uint32_t *blk, uint8_t *init, 
       const uint64_t r = ts::mix64(key + draw * ts::kDrawMul);
       cell = (int)(((r >> 32) * (uint64_t)C) >> 32);
       ++draw;
+      if ((taken[cell >> 5] >> (cell & 31)) & 1u) continue;
     } else {  // bounded fallback, same on the oracle twin
       cell = 0;
-      while ((taken[cell >> 6] >> (cell & 63)) & 1) ++cell;
+      while ((taken[cell >> 5] >> (cell & 31)) & 1u) ++cell;
     }
-    const int w = cell >> 6;
-    const uint64_t bit = 1ull << (cell & 63);
-    const uint64_t tw = w == 0 ? taken[0] : w == 1 ? taken[1] : w == 2 ? taken[2] : taken[3];
-    if (tw & bit) continue;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      taken[k] |= (k == w) ? bit : 0;
-      if (got < K) blocked[k] |= (k == w) ? bit : 0;
-    }
-    if (got >= K && got < K + T)
-      init[(int64_t)(got - K) * N + n] = (uint8_t)cell;
-    else if (got >= K + T)
-      tgt[(int64_t)(got - K - T) * N + n] = (uint8_t)cell;
+    taken[cell >> 5] |= 1u << (cell & 31);
+    if (got < K)
+      blocked[cell >> 5] |= 1u << (cell & 31);
+    else if (got < K + T)
+      init[(int64_t)(got - K) * N + n] = (cell_t)cell;
+    else
+      tgt[(int64_t)(got - K - T) * N + n] = (cell_t)cell;
     ++got;
   }
-#pragma unroll
-  for (int w = 0; w < 8; ++w)
-    if (w < W) blk[(int64_t)w * N + n] = (uint32_t)(blocked[w >> 1] >> ((w & 1) * 32));
+  for (int w = 0; w < W; ++w) blk[(int64_t)w * N + n] = blocked[w];
 }
 
 __global__ __launch_bounds__(256) void k_fill_actions(uint8_t *actions, int64_t N, uint64_t key, int64_t board_offset) {
@@ -986,9 +991,9 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   if (a.op != OP_OBSERVE && (!st->step_count || !st->done)) return TS_ERR_NULL;
   if (((uintptr_t)a.obs & 15u) || ((uintptr_t)a.onehot & 15u)) return TS_ERR_ARG;  // float4 stores
   if (d->n_boards == 0) return TS_OK;
-  a.pos = st->pos;
-  a.init = st->init;
-  a.tgt = st->tgt;
+  a.pos = static_cast<uint8_t *>(st->pos);  // k_large reinterprets these as uint16 above 16x16
+  a.init = static_cast<const uint8_t *>(st->init);
+  a.tgt = static_cast<const uint8_t *>(st->tgt);
   a.blk = st->blk;
   a.step_count = st->step_count;
   a.done = st->done;
@@ -1023,7 +1028,10 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     SmallKernel k = extras ? small_kernel<true>(S, tfix) : small_kernel<false>(S, tfix);
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a);
   } else {
-    const uint32_t per_board = (uint32_t)(3 * C + T + Tt) + (uint32_t)sizeof(LineMasks);
+    const bool wide = S > 16;
+    const uint32_t mask_bytes = wide ? (uint32_t)sizeof(LineMasks<32>) : (uint32_t)sizeof(LineMasks<16>);
+    const uint32_t cell_bytes = (uint32_t)((T + Tt) * (wide ? 2 : 1));
+    const uint32_t per_board = (uint32_t)(3 * C) + mask_bytes + cell_bytes;
     // Measured at 15x15 / 32 tiles (744 MB per launch): 16 lanes per board 129 us, 8: 132 us,
     // 4: 147..167 us, 2: 250 us — few tiles per lane (short dependent chains) and a small LDS
     // carve (more resident waves) beat fewer instructions per board.  Hence: about two tiles
@@ -1035,14 +1043,17 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     }
     const int bpw = kWave >> gshift;
     a.lds_stage_off = align16((uint32_t)(bpw * 3 * C));
-    a.lds_wave_bytes = a.lds_stage_off + align16((uint32_t)(bpw * (sizeof(LineMasks) + T + Tt)));
+    a.lds_wave_bytes = a.lds_stage_off + align16((uint32_t)bpw * (mask_bytes + cell_bytes));
     int waves = TS_WAVES_PER_BLOCK > 4 ? 4 : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > 64u * 1024u) waves >>= 1;
     const int64_t boards_per_block = (int64_t)waves * bpw;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-    hipLaunchKernelGGL(k_large, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, gshift,
-                       (uint32_t)((65536 + S - 1) / S));
+    const uint32_t inv_s = (uint32_t)((65536 + S - 1) / S);
+    if (wide)
+      hipLaunchKernelGGL(k_large<true>, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, gshift, inv_s);
+    else
+      hipLaunchKernelGGL(k_large<false>, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, gshift, inv_s);
   }
   return finish_launch();
 }
@@ -1073,6 +1084,8 @@ const char *ts_status_string(int32_t status) {
 int32_t ts_last_hip_error(void) { return t_last_hip_error; }
 
 int32_t ts_blk_words(int32_t size) { return size < 1 ? 0 : (size * size + 31) / 32; }
+
+int32_t ts_cell_bytes(int32_t size) { return size < 1 || size > TS_MAX_SIZE ? 0 : size <= 16 ? 1 : 2; }
 
 int32_t ts_onehot_channels(const ts_dims *dims) { return dims ? onehot_channels(dims) : 0; }
 
@@ -1166,9 +1179,14 @@ int32_t ts_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int6
   if (dims->n_boards == 0) return TS_OK;
   const int64_t blocks = (dims->n_boards + 255) / 256;
   if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-  hipLaunchKernelGGL(k_generate, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t *)st->blk,
-                     (uint8_t *)st->init, (uint8_t *)st->tgt, dims->n_boards, dims->size, dims->n_tiles, dims->n_targets,
-                     n_obstacles, seed, board_offset);
+  if (dims->size <= 16)
+    hipLaunchKernelGGL(k_generate<uint8_t>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t *)st->blk,
+                       (uint8_t *)st->init, (uint8_t *)st->tgt, dims->n_boards, dims->size, dims->n_tiles, dims->n_targets,
+                       n_obstacles, seed, board_offset);
+  else
+    hipLaunchKernelGGL(k_generate<uint16_t>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t *)st->blk,
+                       (uint16_t *)st->init, (uint16_t *)st->tgt, dims->n_boards, dims->size, dims->n_tiles, dims->n_targets,
+                       n_obstacles, seed, board_offset);
   return finish_launch();
 }
 

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _cabi
-from .levels import pack_levels, unpack_blocked, unpack_cells
+from .levels import cell_dtype, pack_levels, unpack_blocked, unpack_cells
 from .moves import ALL_MOVES, Move
 from .vec_env import _DONE_MSG, VecTilerSliderEnv
 
@@ -76,8 +76,8 @@ class GameState:
             # never read, state.py:84-118), which the level packer would reject as tile cells
             blk1, _, _ = pack_levels(S, [self._blocked_locations], [[]], [[]])
             probe = VecTilerSliderEnv.from_arrays(
-                S, np.repeat(blk1, n, axis=1), np.tile(np.arange(C, dtype=np.uint8), 4)[None, :],
-                np.zeros((1, n), np.uint8), max_steps=_NO_LIMIT, device=self._device)
+                S, np.repeat(blk1, n, axis=1), np.tile(np.arange(C, dtype=cell_dtype(S)), 4)[None, :],
+                np.zeros((1, n), cell_dtype(S)), max_steps=_NO_LIMIT, device=self._device)
             probe.reset()
             probe.step(torch.arange(4, dtype=torch.uint8).repeat_interleave(C))
             dest = probe.positions[0].cpu().numpy().reshape(4, S, S)

@@ -9,7 +9,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-MAX_SIZE = 16
+MAX_SIZE = 32
 MAX_TILES = 255
 
 
@@ -26,6 +26,12 @@ def blk_words(size):
     return (size * size + 31) // 32
 
 
+def cell_dtype(size):
+    """numpy element type of pos / init / tgt: uint8 up to 16x16, uint16 up to 32x32
+    (include/tiler_slider.h: ts_cell_bytes)."""
+    return np.uint8 if size <= 16 else np.uint16
+
+
 def _cells(size, locs, what):
     out = []
     for loc in locs:
@@ -37,7 +43,8 @@ def _cells(size, locs, what):
 
 
 def pack_levels(size, blocked, initial, targets):
-    """Per-board location lists -> (blk uint32[W,N], init uint8[T,N], tgt uint8[Tt,N]) numpy arrays.
+    """Per-board location lists -> (blk uint32[W,N], init cell[T,N], tgt cell[Tt,N]) numpy arrays
+    (cell = uint8 up to 16x16, uint16 above).
 
     Enforces what the kernels rely on and the reference's factory guarantees
     (ref: explainrl/environment/environment.py:221-226): tiles pairwise distinct and never on
@@ -53,8 +60,8 @@ def pack_levels(size, blocked, initial, targets):
     if T > min(MAX_TILES, size * size) or Tt > MAX_TILES:
         raise ValueError(f"too many tiles/targets for a {size}x{size} board: {T}/{Tt}")
     blk = np.zeros((blk_words(size), n), np.uint32)
-    init = np.zeros((T, n), np.uint8)
-    tgt = np.zeros((Tt, n), np.uint8)
+    init = np.zeros((T, n), cell_dtype(size))
+    tgt = np.zeros((Tt, n), cell_dtype(size))
     for b in range(n):
         if len(initial[b]) != T or len(targets[b]) != Tt:
             raise ValueError("every board of a batch needs the same number of tiles and of targets")

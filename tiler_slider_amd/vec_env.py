@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _cabi
-from .levels import blk_words, pack_levels
+from .levels import blk_words, cell_dtype, pack_levels
 from .moves import Move
 
 _DONE_MSG = "Episode is done. Call reset() to start a new episode."  # environment.py:114
@@ -84,7 +84,7 @@ class VecTilerSliderEnv:
     @classmethod
     def from_arrays(cls, size, blk, init, tgt, multi_color=False, max_steps=100, **kw):
         """Packed level arrays (numpy or torch) in the device layout: blk [W,N] 32-bit words,
-        init uint8 [T,N], tgt uint8 [Tt,N]."""
+        init [T,N] and tgt [Tt,N] cell ids (uint8 up to 16x16; uint16 / torch.int16 above)."""
         self = cls.__new__(cls)
         self._setup(size, blk, init, tgt, multi_color, max_steps, kw.pop("device", None), kw.pop("strict", False),
                     kw.pop("auto_reset", False), kw.pop("with_reward", False), kw.pop("with_onehot", False),
@@ -114,8 +114,8 @@ class VecTilerSliderEnv:
         device = _resolve_device(kw.get("device"))
         W = blk_words(size)
         blk = torch.zeros((W, n_boards), dtype=torch.int32, device=device)
-        init = torch.zeros((num_tiles, n_boards), dtype=torch.uint8, device=device)
-        tgt = torch.zeros((num_tiles, n_boards), dtype=torch.uint8, device=device)
+        init = torch.zeros((num_tiles, n_boards), dtype=_cell_torch_dtype(size), device=device)
+        tgt = torch.zeros((num_tiles, n_boards), dtype=_cell_torch_dtype(size), device=device)
         dims = _cabi.Dims(n_boards, size, num_tiles, num_tiles, int(bool(multi_color)), max_steps, 0)
         st = _cabi.State(None, init.data_ptr(), tgt.data_ptr(), blk.data_ptr(), None, None)
         with torch.cuda.device(device):
@@ -132,8 +132,8 @@ class VecTilerSliderEnv:
         self.size, self.multi_color, self.max_steps = int(size), bool(multi_color), int(max_steps)
         self.strict, self.auto_reset = bool(strict), bool(auto_reset)
         self._blk = _to_device(blk, torch.int32, self.device)
-        self._init = _to_device(init, torch.uint8, self.device)
-        self._tgt = _to_device(tgt, torch.uint8, self.device)
+        self._init = _to_device(init, _cell_torch_dtype(self.size), self.device)
+        self._tgt = _to_device(tgt, _cell_torch_dtype(self.size), self.device)
         W = blk_words(self.size)
         if self._blk.dim() != 2 or self._blk.shape[0] != W:
             raise ValueError(f"blk must have shape [{W}, N]")
@@ -227,7 +227,7 @@ class VecTilerSliderEnv:
 
     @property
     def positions(self):
-        """uint8 [T, N] current cell ids (r * size + c)."""
+        """[T, N] current cell ids (r * size + c): uint8 up to 16x16, int16 above."""
         return self._pos
 
     def encode(self, out=None):
@@ -314,10 +314,17 @@ def _resolve_device(device):
     return dev
 
 
+def _cell_torch_dtype(size):
+    # torch has no general uint16 arithmetic; int16 holds the same bits (cell ids < 1024)
+    return torch.uint8 if cell_dtype(size) == np.uint8 else torch.int16
+
+
 def _to_device(a, dtype, device):
     if isinstance(a, np.ndarray):
         if dtype == torch.int32 and a.dtype == np.uint32:
             a = a.view(np.int32)
+        if dtype == torch.int16 and a.dtype == np.uint16:
+            a = a.view(np.int16)
         a = torch.from_numpy(np.ascontiguousarray(a))
     if a.dtype != dtype:
         raise TypeError(f"expected {dtype}, got {a.dtype}")
