@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the multi-rank code path (RCCL group, max-over-ranks reduction, "
+                         "all-gather timings) even with one rank; launch under torch.distributed.run")
     args = ap.parse_args()
 
     import torch
@@ -114,7 +117,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         dist.init_process_group("nccl", device_id=device)
 
     cfg = dict(CONFIGS[args.config])
@@ -135,7 +139,7 @@ def main():
         ring.append(a)
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -164,7 +168,7 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
 
     tm = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
-    if world > 1:
+    if multi:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     wall, dev_ms = float(tm[0]), float(tm[1])
     total_boards = n * world
@@ -184,7 +188,7 @@ def main():
         api = {"value": n * k / dt, "unit": "env-steps/s", "us_per_call": dt / k * 1e6, "steps": k}
 
     gather = None
-    if world > 1 and not args.no_gather:
+    if multi and not args.no_gather:
         gather = time_gathers(env, ring, world, n, dist, torch, device, min(args.steps, 20))
 
     if rank == 0:
@@ -217,7 +221,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -317,3 +317,43 @@ def test_gym_wrapper_and_hipgraph_replay(torch_cuda, oracle):
         np.testing.assert_array_equal(env.positions.cpu().numpy(), ref.pos)
         np.testing.assert_array_equal(env._obs.cpu().numpy(), want["obs"])
         np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref.step_count)
+
+
+def test_fuzzed_shapes_vs_oracle(torch_cuda, oracle):
+    """Seeded fuzz over the whole shape space (S 1..32, any tile / target / obstacle counts, both
+    colour modes, both step modes, ragged N): every output of every step against the oracle."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    rng = np.random.default_rng(0x715311DE)
+    for case in range(40):
+        S = int(rng.integers(1, 33))
+        C = S * S
+        T = int(min(255, rng.integers(0, min(C, 40) + 1)))
+        Tt = T if rng.random() < 0.7 else int(min(255, rng.integers(0, min(C, 40) + 1)))
+        K = int(rng.integers(0, max(1, (C - T) // 2 + 1)))
+        mc = bool(rng.integers(0, 2))
+        autoreset = bool(rng.integers(0, 2))
+        N = int(rng.integers(1, 700))
+        max_steps = int(rng.integers(1, 12))
+        blk, init, _ = oracle.generate(S, T, 0, K, N, seed=100 + case)
+        _, _, tgt = oracle.generate(S, 0, Tt, 0, N, seed=200 + case)
+        ref = oracle.OracleBatch(S, mc, max_steps, blk, init, tgt)
+        env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps,
+                                            auto_reset=autoreset, with_reward=True, with_valid_moves=True,
+                                            with_onehot=C * (1 + T + Tt) <= 20000)
+        ctx = f"case={case} S={S} T={T} Tt={Tt} K={K} mc={mc} autoreset={autoreset} N={N}"
+        np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset(), err_msg=ctx)
+        mode = oracle.MODE_AUTORESET if autoreset else oracle.MODE_STRICT
+        for step in range(6):
+            act = oracle.fill_actions(N, seed=300 + case, step_index=step)
+            obs, done, info = env.step(torch.from_numpy(act))
+            want = ref.step(act, mode=mode, reward=True, valid=True, onehot=env._onehot is not None)
+            np.testing.assert_array_equal(env.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64), err_msg=ctx)
+            np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+            np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref.step_count, err_msg=ctx)
+            np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"], err_msg=ctx)
+            np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
+            np.testing.assert_array_equal(env._valid.cpu().numpy(), want["valid"], err_msg=ctx)
+            if env._onehot is not None:
+                np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
+        np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0, err_msg=ctx)
