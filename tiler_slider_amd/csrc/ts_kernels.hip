@@ -8,17 +8,19 @@
 //
 // Roofline: HBM.  The work is byte/bit indexing; per board-step the kernel reads ~12 B of
 // state and writes 12*S*S B of observation, so the design goal is a streaming-store kernel:
-//   * S <= 8  (k_small): ONE BOARD PER LANE, the whole board as a 32/64-bit bitboard in a
+//   * S <= 8   (k_small): ONE BOARD PER LANE, the whole board as a 32/64-bit bitboard in a
 //     register; a wave owns 64 consecutive boards.  SoA state loads/stores are coalesced
 //     (lane n <-> board n).
-//   * S 9..16 (k_large): 2..16 LANES PER BOARD (chosen per launch), obstacle / tile line
-//     masks in LDS.
+//   * S 9..32  (k_large): 4..16 LANES PER BOARD (chosen per launch), obstacle / tile line
+//     masks in LDS; uint16 cell ids above 16x16.
 //   * observation: each wave builds a byte image [boards][S*S*3] of its boards in LDS, then
 //     streams it out as float4 (one ds_read_b32 + 4 v_cvt_f32_ubyteN + one 16-B global
 //     store per lane): the LDS image is the transpose from "lane = board" to "lane = 16
 //     consecutive output bytes", so every global store instruction writes 1 KiB contiguous.
 //   * waves never talk to each other: each wave has a private LDS carve and only
 //     wave-level ordering is used (DS operations of one wave execute in issue order).
+//   * blocks that share an XCD get one contiguous range of boards (xcd_contiguous_block);
+//     launches that write more than the Infinity Cache holds use nontemporal stores.
 // No MFMA: nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
@@ -42,7 +44,7 @@
 #ifndef TS_LARGE_GSHIFT  // log2(lanes per board) of k_large; -1 = chosen per launch
 #define TS_LARGE_GSHIFT -1
 #endif
-#ifndef TS_ABLATE  // development only: 1 = skip the observation stores, 2 = skip the state stores
+#ifndef TS_ABLATE  // development only (tools/variant_bench.py): 1 = skip the observation stores
 #define TS_ABLATE 0
 #endif
 #ifndef TS_XCD_REMAP
@@ -154,8 +156,6 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 #define TS_SMALL_BOUNDS __launch_bounds__(TS_SMALL_THREADS)
 #endif
 
-// EXTRAS = false compiles the optional outputs (legality mask, reward, one-hot) out, so the
-// plain step / reset / encode path does not carry their registers and code.
 // Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only).  This
 // bijective remap gives the blocks that share an XCD one contiguous range of boards instead of
 // every 8th block:
@@ -176,6 +176,8 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
 
 constexpr int kSmallBatch = 8;  // global loads in flight per lane in the any-T tile / target loops
 
+// EXTRAS = false compiles the optional outputs (legality mask, reward, one-hot) out, so the
+// plain step / reset / encode path does not carry their registers and code.
 template <int S, int TFIX, bool EXTRAS>
 __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   using BB = ts::Bitboard<S>;
