@@ -154,6 +154,8 @@ def main():
                 env.step_async(ring[i & 15])
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
+    # timed region: barrier + synchronize, K steps, synchronize (clock stops when THIS rank's K
+    # steps have finished) + barrier; the slowest rank's time is taken below (MAX over ranks)
     barrier()
     t0 = time.perf_counter()
     ev0.record()
@@ -163,8 +165,9 @@ def main():
         for i in range(args.steps):
             env.step_async(ring[i & 15])
     ev1.record()
-    barrier()
+    torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
+    barrier()
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
 
     tm = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
