@@ -357,3 +357,36 @@ def test_fuzzed_shapes_vs_oracle(torch_cuda, oracle):
             if env._onehot is not None:
                 np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
         np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0, err_msg=ctx)
+
+
+# (S, T, K, multi_color, N): enough boards that every CU holds several blocks at once, on every
+# kernel variant that the BASELINE-sized tests above do not reach.  (A launch asking for exactly
+# 64 KiB of LDS per block once passed every small-N test and corrupted 1..4 % of the boards here.)
+LARGE_BATCH_SHAPES = [
+    (3, 1, 0, False, 300_000), (4, 3, 3, False, 300_000), (4, 6, 2, True, 200_000), (6, 5, 6, True, 200_000),
+    (7, 9, 8, False, 150_000), (8, 2, 12, True, 150_000), (8, 20, 10, True, 150_000), (8, 26, 10, False, 100_000),
+    (9, 4, 9, True, 100_000), (12, 16, 20, False, 60_000), (16, 40, 30, True, 40_000), (20, 6, 30, True, 30_000),
+    (32, 64, 100, False, 12_000),
+]
+
+
+@pytest.mark.parametrize("S,T,K,mc,N", LARGE_BATCH_SHAPES)
+def test_large_batches_vs_oracle(torch_cuda, oracle, S, T, K, mc, N):
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=4242 + S)
+    ref = oracle.OracleBatch(S, mc, 2**30, blk, init, tgt)
+    env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=2**30, auto_reset=True,
+                                        with_reward=True, with_valid_moves=True)
+    assert np.array_equal(env.reset().cpu().numpy(), ref.reset())
+    for step in range(3):
+        act = oracle.fill_actions(N, seed=99, step_index=step)
+        obs, done, info = env.step(torch.from_numpy(act))
+        want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True, valid=True)
+        assert np.array_equal(env.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64))
+        assert np.array_equal(info["flags"].cpu().numpy(), want["flags"])
+        assert np.array_equal(obs.cpu().numpy(), want["obs"])
+        assert np.array_equal(info["reward"].cpu().numpy(), want["reward"])
+        assert np.array_equal(env._valid.cpu().numpy(), want["valid"])
+    if S * S * (1 + 2 * T) * N * 4 < 2_000_000_000:  # one-hot planes where they fit comfortably
+        assert np.array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())

@@ -174,6 +174,9 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
 #endif
 }
 
+// boards per observation pass of k_small (also used by the host to size the LDS carve)
+constexpr int small_obs_boards(int C) { return kWave * 3 * C <= 6144 ? kWave : kWave / 2; }
+
 constexpr int kSmallBatch = 8;  // global loads in flight per lane in the any-T tile / target loops
 
 // EXTRAS = false compiles the optional outputs (legality mask, reward, one-hot) out, so the
@@ -183,7 +186,8 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   using BB = ts::Bitboard<S>;
   using M = typename BB::mask_t;
   constexpr int C = BB::C;
-  constexpr int kImg = kWave * 3 * C;  // bytes, multiple of 16
+  constexpr int kObsBoards = small_obs_boards(C);
+  constexpr int kImg = kObsBoards * 3 * C;  // bytes, multiple of 16 (kObsBoards is 32 or 64)
   constexpr int TR = TFIX > 0 ? TFIX : 1;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -426,24 +430,31 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   }
 
   // ---- observation (state.py:188-211) through the LDS byte image ----
+  // kObsBoards boards per pass: all 64 up to 5x5; two passes of 32 from 6x6 on, which halves
+  // the image (the dominant LDS user there) and doubles the resident waves.
   if (a.obs) {
-    for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
-    wave_sync();
-    if (live) {
-      unsigned char *my = img + lane * (3 * C);
-      for (M m = blk; m; m &= m - 1) my[3 * ts::lsb(m)] = 1;
-      if constexpr (TFIX > 0) {
+    for (int c0 = 0; c0 < nb; c0 += kObsBoards) {
+      if (c0) wave_sync();  // the previous pass has been read out
+      for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
+      wave_sync();
+      const int rel = lane - c0;
+      if (live && rel >= 0 && rel < kObsBoards) {
+        unsigned char *my = img + rel * (3 * C);
+        for (M m = blk; m; m &= m - 1) my[3 * ts::lsb(m)] = 1;
+        if constexpr (TFIX > 0) {
 #pragma unroll
-        for (int t = 0; t < TFIX; ++t) my[3 * q[t] + 1] = (unsigned char)(mc ? t + 1 : 1);
+          for (int t = 0; t < TFIX; ++t) my[3 * q[t] + 1] = (unsigned char)(mc ? t + 1 : 1);
 #pragma unroll
-        for (int t = 0; t < TFIX; ++t) my[3 * tg[t] + 2] = (unsigned char)(mc ? t + 1 : 1);
-      } else {
-        for (int t = 0; t < T; ++t) my[3 * st_np[t * kWave + lane] + 1] = (unsigned char)(mc ? t + 1 : 1);
-        for (int j = 0; j < Tt; ++j) my[3 * st_tg[j * kWave + lane] + 2] = (unsigned char)(mc ? j + 1 : 1);
+          for (int t = 0; t < TFIX; ++t) my[3 * tg[t] + 2] = (unsigned char)(mc ? t + 1 : 1);
+        } else {
+          for (int t = 0; t < T; ++t) my[3 * st_np[t * kWave + lane] + 1] = (unsigned char)(mc ? t + 1 : 1);
+          for (int j = 0; j < Tt; ++j) my[3 * st_tg[j * kWave + lane] + 2] = (unsigned char)(mc ? j + 1 : 1);
+        }
       }
+      wave_sync();
+      const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
+      emit_bytes_as_f32(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.nt != 0);
     }
-    wave_sync();
-    emit_bytes_as_f32(img, a.obs + n0 * (3 * C), nb * 3 * C, lane, a.nt != 0);
   }
 
   // ---- build-defined one-hot planes [board][Ch][S][S] ----
@@ -974,6 +985,13 @@ SmallKernel small_kernel(int S, int tfix) {
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// Dynamic LDS per block stays well below 64 KiB.  A launch asking for exactly 65,536 B is
+// accepted by the runtime but co-resident blocks then corrupt each other's LDS (seen on
+// 8x8 / 20 tiles at >= 100k boards: 1..4 % of the boards wrong, none in the first blocks of each
+// CU) — consistent with the size wrapping to 0 in a 16-bit field.  Blocks shrink to 2 or 1
+// wave(s) instead; a single wave never needs more than ~36 KiB.
+constexpr size_t kMaxBlockLds = 60u * 1024u;
+
 int32_t finish_launch() {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1018,11 +1036,12 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
         if (align16(nbc * (uint32_t)(a.onehot_ch * C)) <= 16u * 1024u) a.oh_boards = nbc;
     }
     const bool need_stage = tfix == 0 || (a.onehot && !a.oh_boards);
-    a.lds_stage_off = align16((uint32_t)(kWave * 3 * C));
+    a.lds_stage_off = align16((uint32_t)(small_obs_boards(C) * 3 * C));
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C));
     int waves = TS_WAVES_PER_BLOCK;
-    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > 64u * 1024u) waves >>= 1;
+    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
+    if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
     const int64_t boards_per_block = (int64_t)waves * kWave;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
@@ -1047,7 +1066,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_stage_off = align16((uint32_t)(bpw * 3 * C));
     a.lds_wave_bytes = a.lds_stage_off + align16((uint32_t)bpw * (mask_bytes + cell_bytes));
     int waves = TS_WAVES_PER_BLOCK > 4 ? 4 : TS_WAVES_PER_BLOCK;
-    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > 64u * 1024u) waves >>= 1;
+    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
+    if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
     const int64_t boards_per_block = (int64_t)waves * bpw;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
