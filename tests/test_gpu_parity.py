@@ -363,7 +363,8 @@ def test_fuzzed_shapes_vs_oracle(torch_cuda, oracle):
 # kernel variant that the BASELINE-sized tests above do not reach.  (A launch asking for exactly
 # 64 KiB of LDS per block once passed every small-N test and corrupted 1..4 % of the boards here.)
 LARGE_BATCH_SHAPES = [
-    (3, 1, 0, False, 300_000), (4, 3, 3, False, 300_000), (4, 6, 2, True, 200_000), (6, 5, 6, True, 200_000),
+    (3, 1, 0, False, 300_000), (4, 3, 3, False, 300_000), (5, 4, 3, True, 200_000), (4, 6, 2, True, 200_000),
+    (6, 5, 6, True, 200_000),
     (7, 9, 8, False, 150_000), (8, 2, 12, True, 150_000), (8, 20, 10, True, 150_000), (8, 26, 10, False, 100_000),
     (9, 4, 9, True, 100_000), (12, 16, 20, False, 60_000), (16, 40, 30, True, 40_000), (20, 6, 30, True, 30_000),
     (32, 64, 100, False, 12_000),
@@ -390,3 +391,22 @@ def test_large_batches_vs_oracle(torch_cuda, oracle, S, T, K, mc, N):
         assert np.array_equal(env._valid.cpu().numpy(), want["valid"])
     if S * S * (1 + 2 * T) * N * 4 < 2_000_000_000:  # one-hot planes where they fit comfortably
         assert np.array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
+
+
+def test_onehot_per_float_fallback_at_scale(torch_cuda, oracle):
+    """8x8 with 30 tiles in multi-colour mode has 61 planes: four boards' one-hot byte image is
+    above the 16 KiB LDS budget, so k_small evaluates every output float from the staged cells."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    S, T, K, N = 8, 30, 4, 20_000
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=31)
+    ref = oracle.OracleBatch(S, True, 2**30, blk, init, tgt)
+    env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=True, max_steps=2**30, with_onehot=True)
+    env.reset()
+    ref.reset()
+    for step in range(2):
+        act = oracle.fill_actions(N, seed=7, step_index=step)
+        obs, done, info = env.step(torch.from_numpy(act))
+        want = ref.step(act, onehot=True)
+        assert np.array_equal(obs.cpu().numpy(), want["obs"])
+        assert np.array_equal(info["onehot"].cpu().numpy(), want["onehot"])
