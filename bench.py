@@ -190,6 +190,28 @@ def main():
         dt = time.perf_counter() - t1
         api = {"value": n * k / dt, "unit": "env-steps/s", "us_per_call": dt / k * 1e6, "steps": k}
 
+    # opt-in compact observation (uint8 instead of float32): reported separately, never mixed with
+    # the headline figure, which is the reference's float32 format
+    compact = None
+    if world == 1 and not cfg["onehot"]:
+        env8 = VecTilerSliderEnv.from_arrays(cfg["size"], env._blk, env._init, env._tgt, multi_color=True,
+                                             max_steps=2**30, device=device, auto_reset=True, obs_dtype="uint8")
+        env8.reset()
+        for i in range(10):
+            env8.step_async(ring[i & 15])
+        k = min(args.steps, 200)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(k):
+            env8.step_async(ring[i & 15])
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / k
+        b8 = algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], False, False) - 9 * cfg["size"] ** 2
+        compact = {"value": n / us * 1e6, "unit": "env-steps/s", "kernel_us": us, "obs": "uint8 [N,S,S,3]",
+                   "algorithmic_bytes_per_board_step": b8, "achieved_GBps": b8 * n / us / 1e3}
+        del env8
+
     gather = None
     if multi and not args.no_gather:
         gather = time_gathers(env, ring, world, n, dist, torch, device, min(args.steps, 20))
@@ -219,6 +241,8 @@ def main():
         }
         if api is not None:
             line["python_step_api"] = api
+        if compact is not None:
+            line["compact_u8_obs"] = compact
         if gather is not None:
             line["allgather"] = gather
         if world == 1 and not args.no_cpu_baseline:

@@ -30,6 +30,7 @@
  *    actions    uint8  [N]              0 UP, 1 DOWN, 2 LEFT, 3 RIGHT
  *    flags      uint8  [N]              TS_FLAG_* bits of the step just taken
  *    obs        float32[N][S][S][3]     == np.stack of the reference observation
+ *    obs_u8     uint8  [N][S][S][3]     the same values, one byte each (opt-in compact form)
  *    onehot     float32[N][Ch][S][S]    Ch = ts_onehot_channels(dims)
  *    reward     int32  [N]
  *    valid      uint8  [N]              bit d set <=> move d changes the board
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 1
+#define TS_ABI_VERSION 2
 #define TS_MAX_SIZE 32   /* cell ids: uint8 up to 16x16, uint16 up to 32x32 (ts_cell_bytes) */
 #define TS_MAX_TILES 255 /* observation stores tile index + 1 in one byte */
 
@@ -105,6 +106,8 @@ typedef struct ts_step_out {
   int32_t *reward; /* [N]           optional, build-defined Manhattan reward */
   float *onehot;   /* [N][Ch][S][S] optional, build-defined one-hot planes */
   uint8_t *valid;  /* [N]           optional, legality mask of the post-move board */
+  uint8_t *obs_u8; /* [N][S][S][3]  optional, the observation as bytes (build-defined compact form:
+                      every value of the reference observation is an integer 0..255) */
 } ts_step_out;
 
 /* --- introspection ------------------------------------------------------- */
@@ -153,6 +156,10 @@ int32_t ts_is_won(const ts_dims *dims, const ts_state *st, uint8_t *won, void *s
 /* get_state_array() of the current positions, for all boards.
  * ref: explainrl/environment/state.py:188-211. */
 int32_t ts_encode(const ts_dims *dims, const ts_state *st, float *obs, void *stream);
+
+/* The observation of ts_encode as uint8 [N][S][S][3] (exact: the reference's values are the
+ * integers 0, 1 or index + 1 <= 255).  A quarter of the bytes; build-defined, not a reference format. */
+int32_t ts_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8, void *stream);
 
 /* Build-defined extensions (absent from the reference, environment.py:5 says reward is
  * "handled separately"; parity unpinned vs the reference, pinned by oracle/):

@@ -29,7 +29,7 @@ class State(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [("flags", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("onehot", C.c_void_p),
-                ("valid", C.c_void_p)]
+                ("valid", C.c_void_p), ("obs_u8", C.c_void_p)]
 
 
 def build(force=False):
@@ -65,6 +65,7 @@ def lib():
         L.tso_valid_moves.argtypes = [DP, SP, P]
         L.tso_encode.argtypes = [DP, SP, P]
         L.tso_won.argtypes = [DP, SP, P]
+        L.tso_encode_u8.argtypes = [DP, SP, P]
         L.tso_encode_onehot.argtypes = [DP, SP, P]
         L.tso_reward.argtypes = [DP, SP, P]
         L.tso_generate.argtypes = [DP, SP, C.c_uint64, C.c_int64, C.c_int32]
@@ -186,7 +187,7 @@ class OracleBatch:
         self._check(lib().tso_reset(C.byref(self.dims), C.byref(self._state()), _p(obs)))
         return obs
 
-    def step(self, actions, mode=MODE_STRICT, obs=True, reward=False, onehot=False, valid=False):
+    def step(self, actions, mode=MODE_STRICT, obs=True, reward=False, onehot=False, valid=False, obs_u8=False):
         actions = np.ascontiguousarray(actions, np.uint8)
         assert actions.shape == (self.n,)
         out = {"flags": np.empty(self.n, np.uint8)}
@@ -198,8 +199,10 @@ class OracleBatch:
             out["onehot"] = np.empty((self.n, self.onehot_channels, self.size, self.size), np.float32)
         if valid:
             out["valid"] = np.empty(self.n, np.uint8)
+        if obs_u8:
+            out["obs_u8"] = np.empty((self.n, self.size, self.size, 3), np.uint8)
         so = StepOut(_p(out["flags"]), _p(out.get("obs")), _p(out.get("reward")), _p(out.get("onehot")),
-                     _p(out.get("valid")))
+                     _p(out.get("valid")), _p(out.get("obs_u8")))
         self._check(lib().tso_step(C.byref(self.dims), C.byref(self._state()), _p(actions), mode, C.byref(so)))
         return out
 
@@ -217,6 +220,11 @@ class OracleBatch:
         obs = self._obs_buf()
         self._check(lib().tso_encode(C.byref(self.dims), C.byref(self._state()), _p(obs)))
         return obs
+
+    def encode_u8(self):
+        o = np.empty((self.n, self.size, self.size, 3), np.uint8)
+        self._check(lib().tso_encode_u8(C.byref(self.dims), C.byref(self._state()), _p(o)))
+        return o
 
     def encode_onehot(self):
         oh = np.empty((self.n, self.onehot_channels, self.size, self.size), np.float32)

@@ -296,6 +296,14 @@ static void emit_extras(const ts_dims *d, const board *b, int64_t n, float *obs,
   if (valid) valid[n] = valid_board(d, b);
 }
 
+/* build-defined compact observation: the float32 observation's values as bytes */
+static void emit_obs_u8(const ts_dims *d, const board *b, int64_t n, uint8_t *obs_u8) {
+  const int C = d->size * d->size;
+  float tmp[TSO_MAX_CELLS * 3];
+  encode_board(d, b, tmp);
+  for (int i = 0; i < 3 * C; ++i) obs_u8[n * 3 * C + i] = (uint8_t)tmp[i];
+}
+
 /* environment.py:82-98  reset */
 int32_t tso_reset(const ts_dims *d, const ts_state *st, float *obs) {
   int rc = check_dims(d);
@@ -366,6 +374,7 @@ int32_t tso_step(const ts_dims *d, const ts_state *st, const uint8_t *actions, u
     }
     out->flags[n] = flags;
     emit_extras(d, &b, n, out->obs, out->reward, out->onehot, out->valid);
+    if (out->obs_u8) emit_obs_u8(d, &b, n, out->obs_u8);
   }
   return TS_OK;
 }
@@ -408,6 +417,20 @@ int32_t tso_encode(const ts_dims *d, const ts_state *st, float *obs) {
     load_level(d, st, n, &b);
     load_tiles(d, st->pos, n, &b);
     emit_extras(d, &b, n, obs, NULL, NULL, NULL);
+  }
+  return TS_OK;
+}
+
+int32_t tso_encode_u8(const ts_dims *d, const ts_state *st, uint8_t *obs_u8) {
+  int rc = check_dims(d);
+  if (rc) return rc;
+  if (!st || !obs_u8 || !st->blk || (d->n_tiles && !st->pos) || (d->n_targets && !st->tgt)) return TS_ERR_NULL;
+#pragma omp parallel for schedule(static) num_threads(tso_num_threads())
+  for (int64_t n = 0; n < d->n_boards; ++n) {
+    board b;
+    load_level(d, st, n, &b);
+    load_tiles(d, st->pos, n, &b);
+    emit_obs_u8(d, &b, n, obs_u8);
   }
   return TS_OK;
 }

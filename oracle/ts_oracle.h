@@ -46,6 +46,7 @@ int32_t tso_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions
 int32_t tso_valid_moves(const ts_dims *dims, const ts_state *st, uint8_t *mask);
 int32_t tso_won(const ts_dims *dims, const ts_state *st, uint8_t *won);
 int32_t tso_encode(const ts_dims *dims, const ts_state *st, float *obs);
+int32_t tso_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8);
 int32_t tso_encode_onehot(const ts_dims *dims, const ts_state *st, float *onehot);
 int32_t tso_reward(const ts_dims *dims, const ts_state *st, int32_t *reward);
 int32_t tso_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int64_t board_offset,

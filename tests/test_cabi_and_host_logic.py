@@ -15,7 +15,7 @@ from conftest import ROOT
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "tiler_slider.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ts_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ts_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(L, sym), f"{sym} declared in include/tiler_slider.h but not exported"
     assert set(declared) == set(_cabi.EXPORTS)
-    assert L.ts_abi_version() == 1
+    assert L.ts_abi_version() == 2
     assert _cabi.limits() == (32, 255)
     assert [L.ts_blk_words(s) for s in (1, 4, 5, 6, 8, 15, 16, 20, 32)] == [1, 1, 1, 2, 2, 8, 8, 13, 32]
     assert [L.ts_cell_bytes(s) for s in (0, 1, 16, 17, 32, 33)] == [0, 1, 1, 2, 2, 0]

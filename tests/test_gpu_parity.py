@@ -410,3 +410,27 @@ def test_onehot_per_float_fallback_at_scale(torch_cuda, oracle):
         want = ref.step(act, onehot=True)
         assert np.array_equal(obs.cpu().numpy(), want["obs"])
         assert np.array_equal(info["onehot"].cpu().numpy(), want["onehot"])
+
+
+@pytest.mark.parametrize("S,T,K,N", [(3, 1, 0, 1000), (4, 2, 2, 300_001), (5, 2, 3, 70_001), (8, 20, 10, 50_003),
+                                     (15, 32, 24, 10_001), (20, 6, 30, 3001)])
+def test_uint8_observation_equals_float32_observation(torch_cuda, oracle, S, T, K, N):
+    """The opt-in compact observation: byte-for-byte the float32 observation's values (ragged N,
+    both kernels, the two-pass path from 6x6 on)."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=17)
+    ref = oracle.OracleBatch(S, True, 50, blk, init, tgt)
+    env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=True, max_steps=50, obs_dtype="uint8")
+    obs = env.reset()
+    assert obs.dtype == torch.uint8 and obs.shape == (N, S, S, 3)
+    want = ref.reset()
+    assert np.array_equal(obs.cpu().numpy(), want.astype(np.uint8))
+    for step in range(3):
+        act = oracle.fill_actions(N, seed=5, step_index=step)
+        obs, done, info = env.step(torch.from_numpy(act))
+        w = ref.step(act, obs_u8=True)
+        assert np.array_equal(obs.cpu().numpy(), w["obs_u8"])
+        assert np.array_equal(w["obs_u8"].astype(np.float32), w["obs"])
+        assert np.array_equal(info["flags"].cpu().numpy(), w["flags"])
+    assert np.array_equal(env.encode().cpu().numpy(), ref.encode_u8())

@@ -15,7 +15,7 @@ SRC = os.path.join(_PKG, "csrc", "ts_kernels.hip")
 HEADERS = [os.path.join(_PKG, "csrc", "ts_core.h"), os.path.join(ROOT, "include", "tiler_slider.h")]
 LIB_PATH = os.path.join(_PKG, "lib", "libtiler_slider_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 OK, ERR_NULL, ERR_DIMS, ERR_LIMIT, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0x08
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
@@ -23,7 +23,7 @@ MODE_STRICT, MODE_AUTORESET = 0, 1
 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
-           "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions")
+           "ts_encode_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions")
 
 
 class Dims(C.Structure):
@@ -38,7 +38,7 @@ class State(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [("flags", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("onehot", C.c_void_p),
-                ("valid", C.c_void_p)]
+                ("valid", C.c_void_p), ("obs_u8", C.c_void_p)]
 
 
 class TilerSliderLibraryError(RuntimeError):
@@ -108,7 +108,7 @@ def lib():
     for name, args in (("ts_reset", [DP, SP, P, P]),
                        ("ts_step", [DP, SP, P, C.c_uint32, C.POINTER(StepOut), P]),
                        ("ts_valid_moves", [DP, SP, P, P]), ("ts_is_won", [DP, SP, P, P]),
-                       ("ts_encode", [DP, SP, P, P]),
+                       ("ts_encode", [DP, SP, P, P]), ("ts_encode_u8", [DP, SP, P, P]),
                        ("ts_encode_onehot", [DP, SP, P, P]), ("ts_reward", [DP, SP, P, P]),
                        ("ts_generate", [DP, SP, C.c_uint64, C.c_int64, C.c_int32, P]),
                        ("ts_fill_actions", [C.c_int64, C.c_uint64, C.c_int64, C.c_int64, P, P])):

@@ -73,6 +73,7 @@ struct KArgs {
   int32_t *reward;
   float *onehot;
   uint8_t *valid;
+  uint8_t *obs_u8;
   int64_t N;
   int32_t T, Tt, mc, max_steps;
   uint32_t op, autoreset;
@@ -134,6 +135,23 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
   }
   const int tail = nfl & 3;  // only on the last, partial tile of odd-sized boards
   if (lane < tail) dst[nf4 * 4 + lane] = (float)img[nf4 * 4 + lane];
+}
+
+// Streams `nbytes` of an LDS byte image out unchanged (the uint8 observation).  VEC = 16 needs
+// dst 16-B aligned (k_small: a tile starts at a multiple of 32 boards); VEC = 4 needs 4-B
+// alignment (k_large: 3*S*S bytes per board times a multiple of 4 boards).
+template <int VEC>
+__device__ __forceinline__ void emit_bytes_raw(const unsigned char *img, uint8_t *dst, int nbytes, int lane) {
+  using vec_t = typename std::conditional<VEC == 16, uint4, uint32_t>::type;
+  const int nv = nbytes / VEC;
+  const vec_t *src = reinterpret_cast<const vec_t *>(img);
+  vec_t *d = reinterpret_cast<vec_t *>(dst);
+#if TS_ABLATE == 1
+  if (nbytes == -12345)
+#endif
+  for (int q = lane; q < nv; q += kWave) d[q] = src[q];
+  const int tail = nbytes - nv * VEC;  // only on a ragged last tile
+  if (lane < tail) dst[nv * VEC + lane] = img[nv * VEC + lane];
 }
 
 template <typename M>
@@ -432,7 +450,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   // ---- observation (state.py:188-211) through the LDS byte image ----
   // kObsBoards boards per pass: all 64 up to 5x5; two passes of 32 from 6x6 on, which halves
   // the image (the dominant LDS user there) and doubles the resident waves.
-  if (a.obs) {
+  if (a.obs || a.obs_u8) {
     for (int c0 = 0; c0 < nb; c0 += kObsBoards) {
       if (c0) wave_sync();  // the previous pass has been read out
       for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
@@ -453,7 +471,8 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
-      emit_bytes_as_f32(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.nt != 0);
+      if (a.obs) emit_bytes_as_f32(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.nt != 0);
+      if (a.obs_u8) emit_bytes_raw<16>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
     }
   }
 
@@ -813,7 +832,7 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
   }
 
   // ---- observation (state.py:188-211) through the LDS byte image ----
-  if (a.obs) {
+  if (a.obs || a.obs_u8) {
     wave_sync();  // the parked obstacle words are dead now
     const int img_bytes = (BPW * 3 * C + 15) & ~15;
     for (int off = lane * 16; off < img_bytes; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
@@ -841,7 +860,8 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
       }
       wave_sync();
     }
-    emit_bytes_as_f32(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.nt != 0);
+    if (a.obs) emit_bytes_as_f32(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.nt != 0);
+    if (a.obs_u8) emit_bytes_raw<4>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 
   // ---- build-defined one-hot planes: every output float evaluated from the staged cells ----
@@ -1009,7 +1029,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   if (Tt && !st->tgt) return TS_ERR_NULL;
   if ((a.op == OP_RESET || (a.op == OP_STEP && a.autoreset)) && T && !st->init) return TS_ERR_NULL;
   if (a.op != OP_OBSERVE && (!st->step_count || !st->done)) return TS_ERR_NULL;
-  if (((uintptr_t)a.obs & 15u) || ((uintptr_t)a.onehot & 15u)) return TS_ERR_ARG;  // float4 stores
+  if (((uintptr_t)a.obs & 15u) || ((uintptr_t)a.onehot & 15u) || ((uintptr_t)a.obs_u8 & 15u)) return TS_ERR_ARG;  // 16-B stores
   if (d->n_boards == 0) return TS_OK;
   a.pos = static_cast<uint8_t *>(st->pos);  // k_large reinterprets these as uint16 above 16x16
   a.init = static_cast<const uint8_t *>(st->init);
@@ -1024,7 +1044,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   a.max_steps = d->max_steps;
   a.onehot_ch = onehot_channels(d);
   {
-    const uint64_t per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);
+    const uint64_t per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);  // (obs_u8 stores are plain)
     a.nt = per_board * (uint64_t)d->n_boards > (uint64_t)TS_NT_THRESHOLD_MB * 1024ull * 1024ull ? 1u : 0u;
   }
   hipStream_t hs = (hipStream_t)stream;
@@ -1138,6 +1158,7 @@ int32_t ts_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions,
   a.reward = out->reward;
   a.onehot = out->onehot;
   a.valid = out->valid;
+  a.obs_u8 = out->obs_u8;
   return launch(dims, st, a, stream);
 }
 
@@ -1168,6 +1189,16 @@ int32_t ts_encode(const ts_dims *dims, const ts_state *st, float *obs, void *str
   KArgs a = {};
   a.op = OP_OBSERVE;
   a.obs = obs;
+  return launch(dims, st, a, stream);
+}
+
+int32_t ts_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8, void *stream) {
+  const int32_t rc = check_dims(dims);
+  if (rc) return rc;
+  if (!st || !obs_u8) return TS_ERR_NULL;
+  KArgs a = {};
+  a.op = OP_OBSERVE;
+  a.obs_u8 = obs_u8;
   return launch(dims, st, a, stream);
 }
 

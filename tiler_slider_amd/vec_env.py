@@ -64,7 +64,7 @@ class VecTilerSliderEnv:
 
     def __init__(self, size, blocked_locations=None, initial_locations=None, target_locations=None,
                  multi_color=False, max_steps=100, *, device=None, strict=False, auto_reset=False,
-                 with_reward=False, with_onehot=False, with_valid_moves=False):
+                 with_reward=False, with_onehot=False, with_valid_moves=False, obs_dtype="float32"):
         """blocked/initial/target_locations: one list of (row, col) per board.
 
         strict      : raise the reference's RuntimeError when any board is stepped after done
@@ -72,13 +72,16 @@ class VecTilerSliderEnv:
                       and flagged `stepped_done`.
         auto_reset  : boards that are done when step() is called are reset in place instead
                       (flag `autoreset`); their returned observation is the reset observation.
+        obs_dtype   : "float32" = the reference's observation format (default); "uint8" = the
+                      same values as bytes, a quarter of the memory traffic (every value of the
+                      reference observation is an integer 0..255, so nothing is lost).
         """
         n = len(initial_locations or [])
         blocked_locations = blocked_locations if blocked_locations is not None else [[] for _ in range(n)]
         target_locations = target_locations if target_locations is not None else [[] for _ in range(n)]
         blk, init, tgt = pack_levels(size, blocked_locations, initial_locations or [], target_locations)
         self._setup(size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-                    with_onehot, with_valid_moves)
+                    with_onehot, with_valid_moves, obs_dtype)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -88,7 +91,7 @@ class VecTilerSliderEnv:
         self = cls.__new__(cls)
         self._setup(size, blk, init, tgt, multi_color, max_steps, kw.pop("device", None), kw.pop("strict", False),
                     kw.pop("auto_reset", False), kw.pop("with_reward", False), kw.pop("with_onehot", False),
-                    kw.pop("with_valid_moves", False))
+                    kw.pop("with_valid_moves", False), kw.pop("obs_dtype", "float32"))
         if kw:
             raise TypeError(f"unexpected arguments {sorted(kw)}")
         return self
@@ -126,7 +129,7 @@ class VecTilerSliderEnv:
 
     # ------------------------------------------------------------------ setup
     def _setup(self, size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-               with_onehot, with_valid_moves):
+               with_onehot, with_valid_moves, obs_dtype="float32"):
         L = _cabi.lib()  # raises when the HIP library is missing: no fallback
         self.device = _resolve_device(device)
         self.size, self.multi_color, self.max_steps = int(size), bool(multi_color), int(max_steps)
@@ -149,7 +152,11 @@ class VecTilerSliderEnv:
         self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
         self._flags = torch.zeros(N, dtype=torch.uint8, device=dev)
         self._actions = torch.zeros(N, dtype=torch.uint8, device=dev)
-        self._obs = torch.zeros((N, self.size, self.size, 3), dtype=torch.float32, device=dev)
+        obs_dtype = {"float32": torch.float32, "uint8": torch.uint8}.get(obs_dtype, obs_dtype)
+        if obs_dtype not in (torch.float32, torch.uint8):
+            raise ValueError("obs_dtype must be 'float32' or 'uint8'")
+        self.obs_dtype = obs_dtype
+        self._obs = torch.zeros((N, self.size, self.size, 3), dtype=obs_dtype, device=dev)
         self.onehot_channels = L.ts_onehot_channels(C.byref(self._dims))
         self._reward = torch.zeros(N, dtype=torch.int32, device=dev) if with_reward else None
         self._onehot = (torch.zeros((N, self.onehot_channels, self.size, self.size), dtype=torch.float32, device=dev)
@@ -157,8 +164,9 @@ class VecTilerSliderEnv:
         self._valid = torch.zeros(N, dtype=torch.uint8, device=dev) if with_valid_moves else None
         self._state = _cabi.State(_ptr(self._pos), _ptr(self._init), _ptr(self._tgt), _ptr(self._blk),
                                   _ptr(self._step_count), _ptr(self._done))
-        self._out = _cabi.StepOut(_ptr(self._flags), _ptr(self._obs), _ptr(self._reward), _ptr(self._onehot),
-                                  _ptr(self._valid))
+        f32 = obs_dtype == torch.float32
+        self._out = _cabi.StepOut(_ptr(self._flags), _ptr(self._obs) if f32 else None, _ptr(self._reward),
+                                  _ptr(self._onehot), _ptr(self._valid), None if f32 else _ptr(self._obs))
         self._mode = _cabi.MODE_AUTORESET if self.auto_reset else _cabi.MODE_STRICT
         self.observation_shape = (self.size, self.size, 3)  # per board, environment.py:59
         self._started = False
@@ -168,7 +176,11 @@ class VecTilerSliderEnv:
     def reset(self):
         """All boards back to their level's initial cells; returns the observation tensor."""
         self._require_open()
-        self._call("ts_reset", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
+        if self.obs_dtype == torch.float32:
+            self._call("ts_reset", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
+        else:
+            self._call("ts_reset", C.byref(self._dims), C.byref(self._state), None)
+            self._call("ts_encode_u8", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
         self._started = True
         return self._obs
 
@@ -233,7 +245,8 @@ class VecTilerSliderEnv:
     def encode(self, out=None):
         """The reference observation of the current boards (state.py:188-211)."""
         out = torch.empty_like(self._obs) if out is None else out
-        self._call("ts_encode", C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        name = "ts_encode" if out.dtype == torch.float32 else "ts_encode_u8"
+        self._call(name, C.byref(self._dims), C.byref(self._state), out.data_ptr())
         return out
 
     def encode_onehot(self, out=None):
