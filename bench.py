@@ -50,6 +50,19 @@ def algorithmic_bytes_per_board_step(size, tiles, onehot, reward, multi_color=Tr
     return read + write
 
 
+def pmc_traffic(config, boards):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic_pmc.json; counters cannot be read from inside this process).  None when no
+    pass exists for this config / batch size."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "traffic_pmc.json"))).get(config)
+    except (OSError, ValueError):
+        return None
+    if not rec or rec.get("boards") != boards:
+        return None
+    return rec
+
+
 def host_cpu_share():
     """Cores this process may actually use: the cgroup CPU quota if there is one, else the
     scheduler affinity (a GPU box hands each GPU's job a share of the host, not all of it)."""
@@ -239,6 +252,12 @@ def main():
                          "algorithmic_bytes_per_launch": bps * n,
                          "note": "working set < 256 MiB Infinity Cache at cfg1/cfg2: rate may exceed pure-HBM"},
         }
+        rec = pmc_traffic(args.config, n)
+        if rec is not None:
+            line["roofline"]["traffic"] = rec["write_bytes"] + rec["fetch_bytes_x2"]
+            line["roofline"]["traffic_source"] = ("rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read "
+                                                  "correction; raw FETCH_SIZE %d B), separate passes, recorded in "
+                                                  "profiles/traffic_pmc.json" % rec["fetch_bytes_raw"])
         if api is not None:
             line["python_step_api"] = api
         if compact is not None:
