@@ -47,6 +47,7 @@ def test_argument_validation_precedes_any_launch():
         assert L.ts_check_dims(C.byref(bad)) == want
     st, out = _cabi.State(), _cabi.StepOut()
     assert L.ts_step(C.byref(ok), C.byref(st), None, 0, C.byref(out), None) == _cabi.ERR_NULL
+    assert L.ts_step(C.byref(ok), C.byref(st), None, 8, C.byref(out), None) == _cabi.ERR_ARG
     assert L.ts_step(None, C.byref(st), None, 0, C.byref(out), None) == _cabi.ERR_NULL
     assert L.ts_reset(C.byref(ok), None, None, None) == _cabi.ERR_NULL
     assert L.ts_reset(C.byref(ok), C.byref(st), None, None) == _cabi.ERR_NULL  # blk missing
@@ -60,6 +61,7 @@ def test_argument_validation_precedes_any_launch():
     out = _cabi.StepOut(C.addressof(buf), None, None, None, None)
     assert L.ts_step(C.byref(empty), C.byref(st), C.addressof(buf), 0, C.byref(out), None) == _cabi.OK
     assert L.ts_step(C.byref(empty), C.byref(st), C.addressof(buf), 8, C.byref(out), None) == _cabi.ERR_ARG
+    assert L.ts_reset(C.byref(empty), C.byref(_cabi.State()), None, None) == _cabi.OK  # empty batch, no buffers
 
 
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):

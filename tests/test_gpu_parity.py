@@ -434,3 +434,12 @@ def test_uint8_observation_equals_float32_observation(torch_cuda, oracle, S, T, 
         assert np.array_equal(w["obs_u8"].astype(np.float32), w["obs"])
         assert np.array_equal(info["flags"].cpu().numpy(), w["flags"])
     assert np.array_equal(env.encode().cpu().numpy(), ref.encode_u8())
+
+
+def test_empty_batch(torch_cuda):
+    from tiler_slider_amd import VecTilerSliderEnv
+    env = VecTilerSliderEnv(4, [], [], [])
+    assert env.num_envs == 0 and env.reset().shape == (0, 4, 4, 3)
+    obs, done, info = env.step(torch_cuda.zeros(0, dtype=torch_cuda.uint8))
+    assert obs.shape == (0, 4, 4, 3) and done.shape == (0,) and info["is_won"].shape == (0,)
+    assert env.get_valid_moves().shape == (0, 4)

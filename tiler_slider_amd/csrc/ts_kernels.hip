@@ -1024,13 +1024,13 @@ int32_t finish_launch() {
 // The one launch path behind ts_reset / ts_step / ts_encode / ts_valid_moves / ...
 int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   const int S = d->size, C = S * S, T = d->n_tiles, Tt = d->n_targets;
+  if (d->n_boards == 0) return TS_OK;  // nothing to do; an empty batch may carry NULL buffers
   if (!st->blk) return TS_ERR_NULL;
   if (T && !st->pos) return TS_ERR_NULL;
   if (Tt && !st->tgt) return TS_ERR_NULL;
   if ((a.op == OP_RESET || (a.op == OP_STEP && a.autoreset)) && T && !st->init) return TS_ERR_NULL;
   if (a.op != OP_OBSERVE && (!st->step_count || !st->done)) return TS_ERR_NULL;
   if (((uintptr_t)a.obs & 15u) || ((uintptr_t)a.onehot & 15u) || ((uintptr_t)a.obs_u8 & 15u)) return TS_ERR_ARG;  // 16-B stores
-  if (d->n_boards == 0) return TS_OK;
   a.pos = static_cast<uint8_t *>(st->pos);  // k_large reinterprets these as uint16 above 16x16
   a.init = static_cast<const uint8_t *>(st->init);
   a.tgt = static_cast<const uint8_t *>(st->tgt);
@@ -1136,6 +1136,7 @@ int32_t ts_check_dims(const ts_dims *dims) { return check_dims(dims); }
 int32_t ts_reset(const ts_dims *dims, const ts_state *st, float *obs, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   if (!st) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_RESET;
@@ -1147,8 +1148,9 @@ int32_t ts_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions,
                 void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
-  if (!st || !out || !actions || !out->flags) return TS_ERR_NULL;
   if (mode & ~TS_MODE_AUTORESET) return TS_ERR_ARG;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
+  if (!st || !out || !actions || !out->flags) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_STEP;
   a.autoreset = (mode & TS_MODE_AUTORESET) ? 1u : 0u;
@@ -1165,6 +1167,7 @@ int32_t ts_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions,
 int32_t ts_valid_moves(const ts_dims *dims, const ts_state *st, uint8_t *mask, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   if (!st || !mask) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_OBSERVE;
@@ -1175,6 +1178,7 @@ int32_t ts_valid_moves(const ts_dims *dims, const ts_state *st, uint8_t *mask, v
 int32_t ts_is_won(const ts_dims *dims, const ts_state *st, uint8_t *won, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   if (!st || !won) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_OBSERVE;
@@ -1185,6 +1189,7 @@ int32_t ts_is_won(const ts_dims *dims, const ts_state *st, uint8_t *won, void *s
 int32_t ts_encode(const ts_dims *dims, const ts_state *st, float *obs, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   if (!st || !obs) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_OBSERVE;
@@ -1195,6 +1200,7 @@ int32_t ts_encode(const ts_dims *dims, const ts_state *st, float *obs, void *str
 int32_t ts_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   if (!st || !obs_u8) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_OBSERVE;
@@ -1205,6 +1211,7 @@ int32_t ts_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8, v
 int32_t ts_encode_onehot(const ts_dims *dims, const ts_state *st, float *onehot, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   if (!st || !onehot) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_OBSERVE;
@@ -1215,6 +1222,7 @@ int32_t ts_encode_onehot(const ts_dims *dims, const ts_state *st, float *onehot,
 int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   if (!st || !reward) return TS_ERR_NULL;
   KArgs a = {};
   a.op = OP_OBSERVE;
@@ -1226,6 +1234,7 @@ int32_t ts_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int6
                     void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
   const int C = dims->size * dims->size;
   if (n_obstacles < 0 || n_obstacles + dims->n_tiles + dims->n_targets > C) return TS_ERR_DIMS;
   if (!st || !st->blk || (dims->n_tiles && !st->init) || (dims->n_targets && !st->tgt)) return TS_ERR_NULL;
