@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void k_fill(f32x4 *dst, int64_t n16, uint32_t 
     const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = bid & 7u;
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
-  const int64_t wave = (int64_t)bid * 4 + (threadIdx.x >> 6);
+  const int64_t wave = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t base = wave * (int64_t)chunk16 * 64;
   for (int i = 0; i < chunk16; ++i) {
     const int64_t q = base + (int64_t)i * 64 + lane;
@@ -48,17 +48,21 @@ __global__ __launch_bounds__(256) void k_fill(f32x4 *dst, int64_t n16, uint32_t 
   if constexpr (POLICY >= 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+extern "C" int mb_fill2(void *dst, int64_t nbytes, uint32_t seed, int policy, int chunk16, int lds_bytes, int mode, int wpb, void *stream);
 extern "C" int mb_fill(void *dst, int64_t nbytes, uint32_t seed, int policy, int chunk16, int lds_bytes, int mode, void *stream) {
+  return mb_fill2(dst, nbytes, seed, policy, chunk16, lds_bytes, mode, 4, stream);
+}
+extern "C" int mb_fill2(void *dst, int64_t nbytes, uint32_t seed, int policy, int chunk16, int lds_bytes, int mode, int wpb, void *stream) {
   const int64_t n16 = nbytes / 16;
   const int64_t waves = (n16 + (int64_t)chunk16 * 64 - 1) / ((int64_t)chunk16 * 64);
-  const uint32_t blocks = (uint32_t)((waves + 3) / 4);
+  const uint32_t blocks = (uint32_t)((waves + wpb - 1) / wpb);
   hipStream_t s = (hipStream_t)stream;
   f32x4 *d = (f32x4 *)dst;
   switch (policy) {
-    case 0: hipLaunchKernelGGL(k_fill<0>, dim3(blocks), dim3(256), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
-    case 1: hipLaunchKernelGGL(k_fill<1>, dim3(blocks), dim3(256), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
-    case 2: hipLaunchKernelGGL(k_fill<2>, dim3(blocks), dim3(256), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
-    default: hipLaunchKernelGGL(k_fill<3>, dim3(blocks), dim3(256), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
+    case 0: hipLaunchKernelGGL(k_fill<0>, dim3(blocks), dim3(64 * wpb), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
+    case 1: hipLaunchKernelGGL(k_fill<1>, dim3(blocks), dim3(64 * wpb), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
+    case 2: hipLaunchKernelGGL(k_fill<2>, dim3(blocks), dim3(64 * wpb), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
+    default: hipLaunchKernelGGL(k_fill<3>, dim3(blocks), dim3(64 * wpb), (size_t)lds_bytes, s, d, n16, seed, chunk16, mode); break;
   }
   return (int)hipGetLastError();
 }
