@@ -10,12 +10,13 @@ from ._cabi import TilerSliderLibraryError, build_library
 from .env import GameState, TilerSliderEnv
 from .factory import TilerSliderEnvFactory, simple_level
 from .gym_wrapper import GymVecTilerSlider
-from .levels import Level, pack_levels, parse_board_string
+from .levels import ImageLoader, Level, pack_levels, parse_board_string
 from .moves import Move
 from .render import TextRender
 from .vec_env import StepInfo, VecTilerSliderEnv
 
 __version__ = "0.1.0"
-__all__ = ["GameState", "Move", "TilerSliderEnv", "TilerSliderEnvFactory", "TextRender", "VecTilerSliderEnv",
+__all__ = ["GameState", "Move", "TilerSliderEnv", "TilerSliderEnvFactory", "ImageLoader", "TextRender",
+           "VecTilerSliderEnv",
            "StepInfo", "GymVecTilerSlider", "Level", "pack_levels", "parse_board_string", "simple_level", "build_library",
            "TilerSliderLibraryError"]

@@ -5,7 +5,7 @@ ImageProcessed: size, blocked_locations, initial_locations, target_locations,
 multiple_colors).  All boards of one batch share size, tile count, target count and
 multi_color; obstacles and cell positions are per board.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -13,13 +13,41 @@ MAX_SIZE = 32
 MAX_TILES = 255
 
 
-@dataclass
-class Level:
-    size: int
-    blocked_locations: list = field(default_factory=list)
-    initial_locations: list = field(default_factory=list)
-    target_locations: list = field(default_factory=list)
-    multiple_colors: bool = False
+class ImageLoader:
+    """The level records of the reference's screenshot loader, without the loader.
+
+    ref: explainrl/environment/dataloader.py:8-27.  `ImageProcessed` is the level schema every
+    environment constructor consumes (environment.py:61-80); `ImageRawData` and the three colour
+    constants are kept so code written against the reference's names imports unchanged.  Parsing
+    the 400 phone screenshots (dataloader.py:29-133) needs OpenCV and is out of this build's scope.
+    """
+
+    BACKGROUND_COLOR = np.array([0, 172, 194])
+    EMPTY_TILE_COLOR = np.array([223, 247, 249])
+    COLOR_TOLERANCE = np.array([10, 10, 10])
+
+    @dataclass
+    class ImageRawData:
+        name: str
+        puzzle_image: np.ndarray
+        level_label: np.ndarray
+        target_moves: np.ndarray
+
+    @dataclass
+    class ImageProcessed:
+        size: int
+        blocked_locations: list
+        initial_locations: list
+        target_locations: list
+        multiple_colors: bool = False
+
+    @classmethod
+    def parse_puzzle_image(cls, target_image, multiple_colors):
+        raise NotImplementedError("screenshot parsing needs OpenCV (absent) and is outside the hot path; "
+                                  "build levels with ImageLoader.ImageProcessed(...) or the factory")
+
+
+Level = ImageLoader.ImageProcessed  # the level record, under a shorter name
 
 
 def blk_words(size):
