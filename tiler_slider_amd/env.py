@@ -38,7 +38,7 @@ class GameState:
         self._device = device
         self._vec = VecTilerSliderEnv(size, [self._blocked_locations], [list(self.current_locations)],
                                       [list(self.target_locations)], multi_color=multi_color, max_steps=_NO_LIMIT,
-                                      device=device)
+                                      device=device, host_mapped=True)
         self._vec.reset()
         self._move_to = None
 
@@ -46,8 +46,10 @@ class GameState:
     def move(self, move):
         v = self._vec
         v._done.zero_()  # GameState has no episode latch: it can keep moving after a win
-        v.step_async(torch.tensor([move.value], dtype=torch.uint8, device=v.device))
-        self.current_locations = unpack_cells(self.size, v.positions[:, 0].cpu().numpy())
+        v._actions[0] = move.value  # buffers are pinned host memory the kernel works on in place
+        v.step_async()
+        v._sync_if_host()
+        self.current_locations = unpack_cells(self.size, v.positions[:, 0].numpy())
         return bool(int(v._flags[0]) & _cabi.FLAG_IS_WON)
 
     # -- state.py:172-186
@@ -56,7 +58,7 @@ class GameState:
 
     # -- state.py:188-211
     def get_state_array(self):
-        return self._vec.encode()[0].cpu().numpy()
+        return self._vec.encode()[0].numpy().copy()
 
     # -- state.py:213-222
     def copy(self):
@@ -80,7 +82,7 @@ class GameState:
                 np.zeros((1, n), cell_dtype(S)), max_steps=_NO_LIMIT, device=self._device)
             probe.reset()
             probe.step(torch.arange(4, dtype=torch.uint8).repeat_interleave(C))
-            dest = probe.positions[0].cpu().numpy().reshape(4, S, S)
+            dest = probe.positions[0].cpu().numpy().astype(np.int64).reshape(4, S, S)
             table = np.empty((S, S, 4, 2), dtype=int)
             for d in range(4):
                 table[:, :, d, 0] = dest[d] // S
@@ -97,18 +99,18 @@ class _BoardView:
         self.size = env.size
         self.multi_color = env.multi_color
         self.target_locations = list(env.target_locations)
-        self.is_blocked = unpack_blocked(env.size, env._vec._blk[:, 0].cpu().numpy().view(np.uint32))
+        self.is_blocked = unpack_blocked(env.size, env._vec._blk[:, 0].numpy().view(np.uint32))
         self.current_locations = []
         self.refresh()
 
     def refresh(self):
-        self.current_locations = unpack_cells(self.size, self._env._vec.positions[:, 0].cpu().numpy())
+        self.current_locations = unpack_cells(self.size, self._env._vec.positions[:, 0].numpy())
 
     def is_won(self):
         return bool(self._env._vec.is_won()[0])
 
     def get_state_array(self):
-        return self._env._vec.encode()[0].cpu().numpy()
+        return self._env._vec.encode()[0].numpy().copy()
 
     def copy(self):
         blocked = [(int(r), int(c)) for r, c in zip(*np.nonzero(self.is_blocked))]
@@ -145,8 +147,8 @@ class TilerSliderEnv:
         if self._vec is None:
             self._vec = VecTilerSliderEnv(self.size, [self.blocked_locations], [self.initial_locations],
                                           [self.target_locations], multi_color=self.multi_color,
-                                          max_steps=self.max_steps, device=self._device)
-        obs = self._vec.reset()[0].cpu().numpy()
+                                          max_steps=self.max_steps, device=self._device, host_mapped=True)
+        obs = self._vec.reset()[0].numpy().copy()  # a fresh array per call, like the reference
         self.state = _BoardView(self)
         self.step_count = 0
         self.done = False
@@ -160,8 +162,10 @@ class TilerSliderEnv:
         if self._vec is None or self.state is None:
             raise RuntimeError("Call reset() before step().")
         v = self._vec
-        v.step_async(torch.tensor([move.value], dtype=torch.uint8, device=v.device))
-        flags = int(v._flags[0])  # device -> host: this adapter is synchronous like the reference
+        v._actions[0] = move.value  # every buffer is pinned host memory the kernel works on in place:
+        v.step_async()              # one launch ...
+        v._sync_if_host()           # ... one stream synchronisation, no device-to-host copies
+        flags = int(v._flags[0])
         self.state.refresh()
         info = {"is_won": bool(flags & _cabi.FLAG_IS_WON), "step_count": self.step_count,
                 "invalid_move": bool(flags & _cabi.FLAG_INVALID_MOVE)}
@@ -171,7 +175,7 @@ class TilerSliderEnv:
             info["timeout"] = True
         self.step_count = int(v.step_count[0])
         self.done = bool(v._done[0])
-        return v._obs[0].cpu().numpy(), self.done, info
+        return v._obs[0].numpy().copy(), self.done, info
 
     def close(self):
         self.state = None
@@ -179,7 +183,7 @@ class TilerSliderEnv:
     def get_valid_moves(self):
         if self.state is None:
             return []
-        mask = self._vec.get_valid_moves()[0].cpu().numpy()
+        mask = self._vec.get_valid_moves()[0].numpy()
         return [m for m in ALL_MOVES if mask[m.value]]
 
     def get_info(self):

@@ -64,7 +64,8 @@ class VecTilerSliderEnv:
 
     def __init__(self, size, blocked_locations=None, initial_locations=None, target_locations=None,
                  multi_color=False, max_steps=100, *, device=None, strict=False, auto_reset=False,
-                 with_reward=False, with_onehot=False, with_valid_moves=False, obs_dtype="float32"):
+                 with_reward=False, with_onehot=False, with_valid_moves=False, obs_dtype="float32",
+                 host_mapped=False):
         """blocked/initial/target_locations: one list of (row, col) per board.
 
         strict      : raise the reference's RuntimeError when any board is stepped after done
@@ -75,13 +76,18 @@ class VecTilerSliderEnv:
         obs_dtype   : "float32" = the reference's observation format (default); "uint8" = the
                       same values as bytes, a quarter of the memory traffic (every value of the
                       reference observation is an integer 0..255, so nothing is lost).
+        host_mapped : keep every buffer in pinned host memory that the GPU reads and writes in
+                      place (zero-copy).  For a handful of boards driven move by move from Python
+                      (the one-board adapters): a step is then one launch plus one stream
+                      synchronisation, with no device-to-host copies.  step() synchronises and
+                      returns CPU tensors.  Pointless for large batches (every byte crosses PCIe).
         """
         n = len(initial_locations or [])
         blocked_locations = blocked_locations if blocked_locations is not None else [[] for _ in range(n)]
         target_locations = target_locations if target_locations is not None else [[] for _ in range(n)]
         blk, init, tgt = pack_levels(size, blocked_locations, initial_locations or [], target_locations)
         self._setup(size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-                    with_onehot, with_valid_moves, obs_dtype)
+                    with_onehot, with_valid_moves, obs_dtype, host_mapped)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -91,7 +97,7 @@ class VecTilerSliderEnv:
         self = cls.__new__(cls)
         self._setup(size, blk, init, tgt, multi_color, max_steps, kw.pop("device", None), kw.pop("strict", False),
                     kw.pop("auto_reset", False), kw.pop("with_reward", False), kw.pop("with_onehot", False),
-                    kw.pop("with_valid_moves", False), kw.pop("obs_dtype", "float32"))
+                    kw.pop("with_valid_moves", False), kw.pop("obs_dtype", "float32"), kw.pop("host_mapped", False))
         if kw:
             raise TypeError(f"unexpected arguments {sorted(kw)}")
         return self
@@ -129,14 +135,15 @@ class VecTilerSliderEnv:
 
     # ------------------------------------------------------------------ setup
     def _setup(self, size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-               with_onehot, with_valid_moves, obs_dtype="float32"):
+               with_onehot, with_valid_moves, obs_dtype="float32", host_mapped=False):
         L = _cabi.lib()  # raises when the HIP library is missing: no fallback
         self.device = _resolve_device(device)
+        self.host_mapped = bool(host_mapped)
         self.size, self.multi_color, self.max_steps = int(size), bool(multi_color), int(max_steps)
         self.strict, self.auto_reset = bool(strict), bool(auto_reset)
-        self._blk = _to_device(blk, torch.int32, self.device)
-        self._init = _to_device(init, _cell_torch_dtype(self.size), self.device)
-        self._tgt = _to_device(tgt, _cell_torch_dtype(self.size), self.device)
+        self._blk = self._place(_to_device(blk, torch.int32, "cpu" if self.host_mapped else self.device))
+        self._init = self._place(_to_device(init, _cell_torch_dtype(self.size), "cpu" if self.host_mapped else self.device))
+        self._tgt = self._place(_to_device(tgt, _cell_torch_dtype(self.size), "cpu" if self.host_mapped else self.device))
         W = blk_words(self.size)
         if self._blk.dim() != 2 or self._blk.shape[0] != W:
             raise ValueError(f"blk must have shape [{W}, N]")
@@ -146,22 +153,21 @@ class VecTilerSliderEnv:
         self.n_tiles, self.n_targets = self._init.shape[0], self._tgt.shape[0]
         self._dims = _cabi.Dims(N, self.size, self.n_tiles, self.n_targets, int(self.multi_color), self.max_steps, 0)
         _cabi.check(L.ts_check_dims(C.byref(self._dims)), "VecTilerSliderEnv")
-        dev = self.device
-        self._pos = self._init.clone()
-        self._step_count = torch.zeros(N, dtype=torch.int32, device=dev)
-        self._done = torch.zeros(N, dtype=torch.uint8, device=dev)
-        self._flags = torch.zeros(N, dtype=torch.uint8, device=dev)
-        self._actions = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self._pos = self._place(self._init.clone())
+        self._step_count = self._zeros(N, torch.int32)
+        self._done = self._zeros(N, torch.uint8)
+        self._flags = self._zeros(N, torch.uint8)
+        self._actions = self._zeros(N, torch.uint8)
         obs_dtype = {"float32": torch.float32, "uint8": torch.uint8}.get(obs_dtype, obs_dtype)
         if obs_dtype not in (torch.float32, torch.uint8):
             raise ValueError("obs_dtype must be 'float32' or 'uint8'")
         self.obs_dtype = obs_dtype
-        self._obs = torch.zeros((N, self.size, self.size, 3), dtype=obs_dtype, device=dev)
+        self._obs = self._zeros((N, self.size, self.size, 3), obs_dtype)
         self.onehot_channels = L.ts_onehot_channels(C.byref(self._dims))
-        self._reward = torch.zeros(N, dtype=torch.int32, device=dev) if with_reward else None
-        self._onehot = (torch.zeros((N, self.onehot_channels, self.size, self.size), dtype=torch.float32, device=dev)
+        self._reward = self._zeros(N, torch.int32) if with_reward else None
+        self._onehot = (self._zeros((N, self.onehot_channels, self.size, self.size), torch.float32)
                         if with_onehot else None)
-        self._valid = torch.zeros(N, dtype=torch.uint8, device=dev) if with_valid_moves else None
+        self._valid = self._zeros(N, torch.uint8) if with_valid_moves else None
         self._state = _cabi.State(_ptr(self._pos), _ptr(self._init), _ptr(self._tgt), _ptr(self._blk),
                                   _ptr(self._step_count), _ptr(self._done))
         f32 = obs_dtype == torch.float32
@@ -172,6 +178,26 @@ class VecTilerSliderEnv:
         self._started = False
         self._closed = False
 
+    # buffers live on the GPU, or (host_mapped) in pinned host memory the GPU addresses directly
+    def _zeros(self, shape, dtype):
+        if self.host_mapped:
+            t = torch.zeros(shape, dtype=dtype)
+            return t.pin_memory() if t.numel() else t
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def _empty(self, shape, dtype):
+        if self.host_mapped:
+            t = torch.empty(shape, dtype=dtype)
+            return t.pin_memory() if t.numel() else t
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _place(self, t):
+        return t.pin_memory() if self.host_mapped and t.numel() and not t.is_pinned() else t
+
+    def _sync_if_host(self):
+        if self.host_mapped:
+            torch.cuda.current_stream(self.device).synchronize()
+
     # ------------------------------------------------------------------ reference API
     def reset(self):
         """All boards back to their level's initial cells; returns the observation tensor."""
@@ -181,6 +207,7 @@ class VecTilerSliderEnv:
         else:
             self._call("ts_reset", C.byref(self._dims), C.byref(self._state), None)
             self._call("ts_encode_u8", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
+        self._sync_if_host()
         self._started = True
         return self._obs
 
@@ -195,6 +222,7 @@ class VecTilerSliderEnv:
         if self.strict and not self.auto_reset and bool(self._done.any()):
             raise RuntimeError(_DONE_MSG)
         self.step_async(act)
+        self._sync_if_host()
         if self.strict and bool((self._flags & _cabi.FLAG_BAD_ACTION).any()):
             raise ValueError("actions must be Move values 0..3")  # state.py:43-45
         return self._obs, self._done.view(torch.bool), self._info()
@@ -209,10 +237,11 @@ class VecTilerSliderEnv:
     def get_valid_moves(self):
         """bool [N, 4]: column d is True where Move(d) would change the board."""
         self._require_open()
-        mask = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        mask = self._empty(self.num_envs, torch.uint8)
         if not self._started:  # environment.py:156-157: [] before reset
-            return torch.zeros((self.num_envs, 4), dtype=torch.bool, device=self.device)
+            return torch.zeros((self.num_envs, 4), dtype=torch.bool, device=mask.device)
         self._call("ts_valid_moves", C.byref(self._dims), C.byref(self._state), mask.data_ptr())
+        self._sync_if_host()
         return _expand_mask(mask)
 
     def get_info(self):
@@ -244,29 +273,32 @@ class VecTilerSliderEnv:
 
     def encode(self, out=None):
         """The reference observation of the current boards (state.py:188-211)."""
-        out = torch.empty_like(self._obs) if out is None else out
+        out = self._empty(tuple(self._obs.shape), self._obs.dtype) if out is None else out
         name = "ts_encode" if out.dtype == torch.float32 else "ts_encode_u8"
         self._call(name, C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        self._sync_if_host()
         return out
 
     def encode_onehot(self, out=None):
         """Build-defined one-hot planes float32 [N, Ch, S, S] (see include/tiler_slider.h)."""
         if out is None:
-            out = torch.empty((self.num_envs, self.onehot_channels, self.size, self.size), dtype=torch.float32,
-                              device=self.device)
+            out = self._empty((self.num_envs, self.onehot_channels, self.size, self.size), torch.float32)
         self._call("ts_encode_onehot", C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        self._sync_if_host()
         return out
 
     def reward(self, out=None):
         """Build-defined Manhattan reward int32 [N] (see include/tiler_slider.h)."""
-        out = torch.empty(self.num_envs, dtype=torch.int32, device=self.device) if out is None else out
+        out = self._empty(self.num_envs, torch.int32) if out is None else out
         self._call("ts_reward", C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        self._sync_if_host()
         return out
 
     def is_won(self):
         """bool [N]: GameState.is_won() of the current boards (state.py:172-186)."""
-        won = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        won = self._empty(self.num_envs, torch.uint8)
         self._call("ts_is_won", C.byref(self._dims), C.byref(self._state), won.data_ptr())
+        self._sync_if_host()
         return won.view(torch.bool)
 
     # ------------------------------------------------------------------ internals
@@ -286,9 +318,10 @@ class VecTilerSliderEnv:
                 raise TypeError(f"actions tensor must hold integers, got {actions.dtype}")
             if actions.shape != (self.num_envs,):
                 raise ValueError(f"actions must have shape ({self.num_envs},)")
-            if actions.dtype == torch.uint8 and actions.device == self.device and actions.is_contiguous():
+            if (not self.host_mapped and actions.dtype == torch.uint8 and actions.device == self.device
+                    and actions.is_contiguous()):
                 return actions
-            a = actions.to(self.device, non_blocking=True)
+            a = actions.to(self._actions.device, non_blocking=True)
             if a.dtype != torch.uint8:  # anything outside a byte becomes 255 = "bad action" for the kernel
                 a = torch.where((a < 0) | (a > 255), torch.full_like(a, 255), a)
             self._actions.copy_(a)
