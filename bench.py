@@ -276,13 +276,23 @@ def main():
 
 
 def time_gathers(env, ring, world, n, dist, torch, device, steps):
-    """Step + hand-off to a single learner, two ways: (a) RCCL all-gather of the float32
+    """Step + hand-off to a single learner, three ways: (a) RCCL all-gather of the float32
     observations (what north_star names); (b) all-gather of the compact state (cell ids) and
-    re-encoding on the learner side with ts_encode."""
+    re-encoding on the learner side with ts_encode; (c) all-gather of uint8 observations and one
+    ts_expand_u8 on the learner."""
     from tiler_slider_amd.distributed import ObservationGatherer
     g = ObservationGatherer(env, world)
     out = {}
-    for name, fn in (("obs_f32", g.gather_observations), ("compact_state_then_encode", g.gather_compact_and_encode)):
+    env8 = None
+    modes = [("obs_f32", env, g.gather_observations), ("compact_state_then_encode", env, g.gather_compact_and_encode)]
+    if not (env._onehot is not None):
+        from tiler_slider_amd import VecTilerSliderEnv
+        env8 = VecTilerSliderEnv.from_arrays(env.size, env._blk, env._init, env._tgt, multi_color=env.multi_color,
+                                             max_steps=env.max_steps, device=device, auto_reset=True, obs_dtype="uint8")
+        env8.reset()
+        g8 = ObservationGatherer(env8, world)
+        modes.append(("obs_u8_then_expand", env8, g8.gather_u8_and_expand))
+    for name, env, fn in modes:
         fn()
         dist.barrier()
         torch.cuda.synchronize(device)
@@ -291,11 +301,12 @@ def time_gathers(env, ring, world, n, dist, torch, device, steps):
             env.step_async(ring[i & 15])
             fn()
         torch.cuda.synchronize(device)
-        dist.barrier()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.barrier()
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         out[name] = {"value": n * world * steps / float(dt[0]), "unit": "env-steps/s", "steps": steps,
                      "bytes_per_rank_per_step": g.bytes_per_step[name]}
+    del env8
     return out
 
 

@@ -161,6 +161,11 @@ int32_t ts_encode(const ts_dims *dims, const ts_state *st, float *obs, void *str
  * integers 0, 1 or index + 1 <= 255).  A quarter of the bytes; build-defined, not a reference format. */
 int32_t ts_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8, void *stream);
 
+/* dst[i] = (float)src[i] for i < count: turns compact uint8 observations (ts_step_out.obs_u8,
+ * ts_encode_u8, or bytes received from another GPU) into the reference's float32 format.  src 4-B
+ * aligned, dst 16-B aligned.  Build-defined helper; the values are exactly ts_encode's. */
+int32_t ts_expand_u8(const uint8_t *src, float *dst, int64_t count, void *stream);
+
 /* Build-defined extensions (absent from the reference, environment.py:5 says reward is
  * "handled separately"; parity unpinned vs the reference, pinned by oracle/):
  *   one-hot: plane 0 obstacles; multi_color: plane 1+i tile i, plane 1+T+j target j;

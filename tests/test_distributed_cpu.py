@@ -29,13 +29,17 @@ class _OracleShardEnv:
 
     def step(self, orc, i):
         act = orc.fill_actions(self.num_envs, seed=5, step_index=i, board_offset=self.lo)
-        self._obs.copy_(torch.from_numpy(self.b.step(act, mode=orc.MODE_AUTORESET)["obs"]))
+        self._obs.copy_(torch.from_numpy(self.b.step(act, mode=orc.MODE_AUTORESET)["obs"]).to(self._obs.dtype))
 
 
 def _oracle_encode(env, pos, tgt, blk, out):
     from oracle import binding as orc
     b = orc.OracleBatch(S, True, 2**30, blk.numpy().view(np.uint32), pos.numpy(), tgt.numpy())
     out.copy_(torch.from_numpy(b.encode()))
+
+
+def _cpu_expand(env, src, dst):
+    dst.copy_(src.to(torch.float32))
 
 
 def _worker(rank, world, port, q):
@@ -45,14 +49,19 @@ def _worker(rank, world, port, q):
     lo, hi = shard_bounds(TOTAL, world, rank)
     env = _OracleShardEnv(orc, lo, hi)
     g = ObservationGatherer(env, world, encode_fn=_oracle_encode)
+    env8 = _OracleShardEnv(orc, lo, hi)
+    env8._obs = env8._obs.to(torch.uint8)
+    g8 = ObservationGatherer(env8, world, encode_fn=_oracle_encode, expand_fn=_cpu_expand)
     ok = True
     whole = _OracleShardEnv(orc, 0, TOTAL)  # the single-process batch
     for i in range(STEPS):
         env.step(orc, i)
         whole.step(orc, i)
+        env8.step(orc, i)
         a = g.gather_observations().clone()
         b = g.gather_compact_and_encode().clone()
-        ok &= torch.equal(a, whole._obs) and torch.equal(b, whole._obs)
+        c = g8.gather_u8_and_expand().clone()
+        ok &= torch.equal(a, whole._obs) and torch.equal(b, whole._obs) and torch.equal(c, whole._obs)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

@@ -443,3 +443,19 @@ def test_empty_batch(torch_cuda):
     obs, done, info = env.step(torch_cuda.zeros(0, dtype=torch_cuda.uint8))
     assert obs.shape == (0, 4, 4, 3) and done.shape == (0,) and info["is_won"].shape == (0,)
     assert env.get_valid_moves().shape == (0, 4)
+
+
+def test_expand_u8(torch_cuda):
+    """ts_expand_u8: bytes -> float32, any count (vector body + up to three trailing values)."""
+    torch = torch_cuda
+    import ctypes as C
+    from tiler_slider_amd import _cabi
+    L = _cabi.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for count in (0, 1, 3, 4, 5, 1023, 4096, 1_000_003, 80_000_000):
+        src = torch.randint(0, 256, (max(count, 1),), dtype=torch.uint8, device="cuda")
+        dst = torch.full((max(count, 1) + 4,), -1.0, dtype=torch.float32, device="cuda")
+        _cabi.check(L.ts_expand_u8(src.data_ptr(), dst.data_ptr(), count, st), "ts_expand_u8")
+        assert torch.equal(dst[:count], src[:count].to(torch.float32))
+        assert bool((dst[count:] == -1.0).all())  # nothing past the end is touched
+    assert L.ts_expand_u8(None, None, 8, st) == _cabi.ERR_NULL and L.ts_expand_u8(None, None, -1, st) == _cabi.ERR_DIMS
