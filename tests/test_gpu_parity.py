@@ -128,6 +128,7 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     # stand-alone entry points on the final state
     np.testing.assert_array_equal(env.get_valid_moves().cpu().numpy(),
                                   (ref.valid_moves()[:, None] >> np.arange(4)) & 1 != 0)
+    np.testing.assert_array_equal(env.valid_move_bits().cpu().numpy(), ref.valid_moves())
     np.testing.assert_array_equal(env.encode().cpu().numpy(), ref.encode())
     np.testing.assert_array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
     np.testing.assert_array_equal(env.reward().cpu().numpy(), ref.reward())

@@ -244,6 +244,15 @@ class VecTilerSliderEnv:
         self._sync_if_host()
         return _expand_mask(mask)
 
+    def valid_move_bits(self, out=None):
+        """uint8 [N]: bit d set where Move(d) would change the board — the kernel's raw output,
+        without the [N, 4] bool expansion of get_valid_moves() (one launch, nothing else)."""
+        self._require_open()
+        out = self._empty(self.num_envs, torch.uint8) if out is None else out
+        self._call("ts_valid_moves", C.byref(self._dims), C.byref(self._state), out.data_ptr())
+        self._sync_if_host()
+        return out
+
     def get_info(self):
         """ref: environment.py:173-194, batched."""
         if not self._started or self._closed:
