@@ -655,10 +655,13 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
     const int n16 = BPW * (int)sizeof(Masks) / 16;
     for (int i = lane; i < n16; i += kWave) z[i] = make_uint4(0, 0, 0, 0);
   }
+  // (ts_is_won / ts_reward look at cells only: no obstacle masks needed)
+  const bool need_obstacles = a.op != OP_OBSERVE || a.obs || a.obs_u8 || a.onehot || a.valid;
   uint32_t *words = reinterpret_cast<uint32_t *>(img) + g * kWords;
-  for (int w = j; w < kWords; w += G) words[w] = (live && w < W) ? a.blk[(int64_t)w * N + n] : 0u;
+  if (need_obstacles)
+    for (int w = j; w < kWords; w += G) words[w] = (live && w < W) ? a.blk[(int64_t)w * N + n] : 0u;
   wave_sync();
-  for (int r = j; r < S; r += G) {
+  for (int r = j; r < S && need_obstacles; r += G) {
     const int bit0 = r * S, w0 = bit0 >> 5, sh = bit0 & 31;
     uint64_t two = (uint64_t)words[w0];
     if (w0 + 1 < kWords) two |= (uint64_t)words[w0 + 1] << 32;
