@@ -34,6 +34,8 @@ CONFIGS = {
     "cfg4": dict(size=15, tiles=32, obstacles=24, boards=1 << 18, onehot=False, reward=False),
     # not in BASELINE.json: exercises the any-tile-count path of the one-lane-per-board kernel
     "s8t20": dict(size=8, tiles=20, obstacles=10, boards=1 << 19, onehot=False, reward=False),
+    "s9t4": dict(size=9, tiles=4, obstacles=9, boards=1 << 19, onehot=False, reward=False),
+    "s12t8": dict(size=12, tiles=8, obstacles=16, boards=1 << 18, onehot=False, reward=False),
 }
 
 

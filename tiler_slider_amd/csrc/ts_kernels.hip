@@ -1087,15 +1087,15 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const bool wide = S > 16;
     const uint32_t mask_bytes = wide ? (uint32_t)sizeof(LineMasks<32>) : (uint32_t)sizeof(LineMasks<16>);
     const uint32_t cell_bytes = (uint32_t)((T + Tt) * (wide ? 2 : 1));
-    const uint32_t per_board = (uint32_t)(3 * C) + mask_bytes + cell_bytes;
-    // Measured at 15x15 / 32 tiles (744 MB per launch): 16 lanes per board 129 us, 8: 132 us,
-    // 4: 147..167 us, 2: 250 us — few tiles per lane (short dependent chains) and a small LDS
-    // carve (more resident waves) beat fewer instructions per board.  Hence: about two tiles
-    // per lane, and at most ~8 KiB of LDS per wave.
+    // Lanes per board, from a sweep of 13 shapes x {4, 8, 16} (profiles/r01_lanes_per_board_sweep.log):
+    // the fewest lanes (= most boards per wave, least fixed work per board) for which a wave
+    // still writes at most ~16 KiB of observation and no lane carries more than three tiles.
+    // Picks the measured best in every swept shape: 9x9/T4 -> 4, 9x9/T16, 10x10, 12x12 -> 8,
+    // 14x14 and larger (incl. 15x15/T32) -> 16.
     int gshift = TS_LARGE_GSHIFT;
     if (gshift < 0) {
-      gshift = 1;
-      while (gshift < 4 && ((uint32_t)(kWave >> gshift) * per_board > 8u * 1024u || (T + 1) / 2 > (1 << gshift))) ++gshift;
+      gshift = 2;
+      while (gshift < 4 && ((uint32_t)(kWave >> gshift) * 12u * (uint32_t)C > 16u * 1024u || (T + (1 << gshift) - 1) >> gshift > 3)) ++gshift;
     }
     const int bpw = kWave >> gshift;
     a.lds_stage_off = align16((uint32_t)(bpw * 3 * C));

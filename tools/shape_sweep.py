@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Development tool: step() throughput and algorithmic bandwidth over a sweep of board shapes."""
+import os, sys, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from tiler_slider_amd import VecTilerSliderEnv
+
+SHAPES = [(3, 1, 0), (4, 2, 2), (4, 4, 2), (5, 2, 3), (5, 6, 3), (6, 3, 4), (7, 5, 6), (8, 4, 8), (8, 12, 8), (9, 4, 9),
+          (10, 5, 10), (12, 8, 16), (14, 20, 20), (15, 32, 24), (16, 16, 24), (20, 10, 40), (24, 30, 60), (32, 32, 100)]
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+print("   S    T    K    boards   out MB    us/step   steps/s    alg GB/s   % of 8 TB/s")
+for S, T, K in SHAPES:
+    n = max(4096, min(1 << 20, (500_000_000 // (12 * S * S)) // 256 * 256))
+    env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=3, multi_color=True, max_steps=2**30,
+                                   auto_reset=True)
+    env.reset()
+    act = torch.randint(0, 4, (n,), dtype=torch.uint8, device=env.device)
+    ts = []
+    for r in range(4):
+        for i in range(3):
+            env.step_async(act)
+        e0.record()
+        for i in range(20):
+            env.step_async(act)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+    us = statistics.median(ts)
+    bps = bench.algorithmic_bytes_per_board_step(S, T, False, False) + (T * 2 if S > 16 else 0) * 1  # 16-bit cells above 16x16
+    gbs = bps * n / us / 1e3
+    print(f"{S:4d} {T:4d} {K:4d} {n:9d} {12 * S * S * n / 1e6:8.0f} {us:10.1f} {n / us * 1e6:10.3e} {gbs:10.0f} {gbs / 80:10.1f}", flush=True)
+    del env

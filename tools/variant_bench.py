@@ -47,6 +47,9 @@ def run(a):
     from tiler_slider_amd import VecTilerSliderEnv, _cabi
     manifest = json.load(open(os.path.join(VDIR, "manifest.json")))
     names = [n for n in manifest if not a.only or n in a.only.split(",")]
+    if a.shape:
+        S_, T_, K_, N_ = (int(x) for x in a.shape.split(","))
+        bench.CONFIGS[a.config] = dict(size=S_, tiles=T_, obstacles=K_, boards=N_, onehot=False, reward=False)
     cfg = dict(bench.CONFIGS[a.config])
     if a.boards:
         cfg["boards"] = a.boards
@@ -127,6 +130,7 @@ if __name__ == "__main__":
     r.add_argument("--rounds", type=int, default=10)
     r.add_argument("--steps", type=int, default=100)
     r.add_argument("--only")
+    r.add_argument("--shape", help="S,T,K,N: ad-hoc shape registered under --config's name")
     r.add_argument("--no-check", action="store_true")
     r.add_argument("--tag", default="")
     args = ap.parse_args()
