@@ -36,6 +36,7 @@ CONFIGS = {
     "s8t20": dict(size=8, tiles=20, obstacles=10, boards=1 << 19, onehot=False, reward=False),
     "s9t4": dict(size=9, tiles=4, obstacles=9, boards=1 << 19, onehot=False, reward=False),
     "s12t8": dict(size=12, tiles=8, obstacles=16, boards=1 << 18, onehot=False, reward=False),
+    "s32t64": dict(size=32, tiles=64, obstacles=100, boards=1 << 15, onehot=False, reward=False),
 }
 
 

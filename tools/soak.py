@@ -21,7 +21,8 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else cfg["boards"]
 orc.lib().tso_set_num_threads(bench.host_cpu_share())
 blk, init, tgt = orc.generate(cfg["size"], cfg["tiles"], cfg["tiles"], cfg["obstacles"], n, seed=bench.LEVEL_SEED)
 ref = orc.OracleBatch(cfg["size"], True, 37, blk, init, tgt)  # short episodes: wins, timeouts, autoresets all occur
-env = VecTilerSliderEnv.from_arrays(cfg["size"], blk, init, tgt, multi_color=True, max_steps=37, auto_reset=True)
+extras = dict(with_reward=True, with_valid_moves=True, with_onehot=cfg["onehot"])
+env = VecTilerSliderEnv.from_arrays(cfg["size"], blk, init, tgt, multi_color=True, max_steps=37, auto_reset=True, **extras)
 env.reset()
 ref.reset()
 t0 = time.time()
@@ -29,15 +30,19 @@ bad = 0
 for i in range(K):
     a = orc.fill_actions(n, seed=bench.ACTION_SEED, step_index=i)
     env.step_async(torch.from_numpy(a).cuda())
-    want = ref.step(a, mode=orc.MODE_AUTORESET, obs=(i % 50 == 49))
+    full = i % 50 == 49
+    want = ref.step(a, mode=orc.MODE_AUTORESET, obs=full, reward=full, valid=full, onehot=full and cfg["onehot"])
     got = env._flags.cpu().numpy()
     if not np.array_equal(got, want["flags"]):
         bad += 1
         print(f"step {i}: flags differ on {int((got != want['flags']).sum())} boards", flush=True)
     if i % 50 == 49:
         same = np.array_equal(env._obs.cpu().numpy(), want["obs"]) and np.array_equal(env.positions.cpu().numpy(), ref.pos)
+        same &= np.array_equal(env._reward.cpu().numpy(), want["reward"]) and np.array_equal(env._valid.cpu().numpy(), want["valid"])
+        if cfg["onehot"]:
+            same &= np.array_equal(env._onehot.cpu().numpy(), want["onehot"])
         bad += not same
-        print(f"step {i + 1}/{K}: obs+pos {'equal' if same else 'DIFFER'}; wins so far flagged this step: "
+        print(f"step {i + 1}/{K}: obs+pos+reward+valid{'+onehot' if cfg['onehot'] else ''} {'equal' if same else 'DIFFER'}; wins so far flagged this step: "
               f"{int((want['flags'] & 4 != 0).sum())}, autoresets: {int((want['flags'] & 32 != 0).sum())}  "
               f"[{time.time() - t0:.0f} s]", flush=True)
 ok = bad == 0 and np.array_equal(env.positions.cpu().numpy(), ref.pos) and np.array_equal(env.step_count.cpu().numpy(), ref.step_count) \
