@@ -79,7 +79,8 @@ def test_gamestate_adapter_matches_reference_golden(torch_cuda, name):
 RANDOM_SHAPES = [
     (1, 1, 0, False, 67, 5), (2, 1, 1, True, 130, 7), (3, 1, 0, False, 1027, 9), (3, 2, 2, True, 513, 9),
     (4, 2, 2, True, 4099, 12), (4, 2, 2, False, 4099, 12), (4, 3, 3, False, 1000, 12), (4, 5, 4, True, 777, 30),
-    (2, 4, 0, False, 200, 6), (5, 4, 3, True, 1025, 12), (8, 3, 20, False, 700, 12),
+    (2, 4, 0, False, 200, 6), (5, 4, 3, True, 1025, 12), (8, 3, 20, False, 700, 12), (3, 6, 1, True, 300, 9),
+    (6, 8, 5, False, 500, 20), (8, 8, 8, True, 900, 20), (7, 6, 3, False, 333, 15),
     (5, 2, 3, True, 4099, 12), (5, 2, 3, False, 2049, 12), (5, 7, 5, False, 1500, 40), (6, 1, 6, True, 999, 10),
     (6, 9, 6, True, 640, 40), (7, 2, 9, False, 1111, 10), (7, 12, 9, True, 321, 40), (8, 2, 12, True, 2050, 10),
     (8, 30, 10, False, 259, 40), (8, 60, 2, True, 131, 40),
@@ -365,7 +366,7 @@ def test_fuzzed_shapes_vs_oracle(torch_cuda, oracle):
 # 64 KiB of LDS per block once passed every small-N test and corrupted 1..4 % of the boards here.)
 LARGE_BATCH_SHAPES = [
     (3, 1, 0, False, 300_000), (4, 3, 3, False, 300_000), (5, 4, 3, True, 200_000), (4, 6, 2, True, 200_000),
-    (6, 5, 6, True, 200_000),
+    (6, 5, 6, True, 200_000), (8, 8, 8, False, 150_000), (5, 7, 5, True, 200_000),
     (7, 9, 8, False, 150_000), (8, 2, 12, True, 150_000), (8, 20, 10, True, 150_000), (8, 26, 10, False, 100_000),
     (9, 4, 9, True, 100_000), (12, 16, 20, False, 60_000), (16, 40, 30, True, 40_000), (20, 6, 30, True, 30_000),
     (32, 64, 100, False, 12_000),

@@ -47,6 +47,9 @@
 #ifndef TS_ABLATE  // development only (tools/variant_bench.py): 1 = skip the observation stores
 #define TS_ABLATE 0
 #endif
+#ifndef TS_MAX_TFIX  // largest tile count with a register-resident instantiation of k_small (4, 6 or 8)
+#define TS_MAX_TFIX 8
+#endif
 #ifndef TS_XCD_REMAP
 #define TS_XCD_REMAP 1
 #endif
@@ -164,7 +167,7 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 }
 
 // ------------------------------------------------------------------------------------------
-// k_small: S <= 8, one board per lane.  TFIX in 1..4: n_tiles == n_targets == TFIX, positions
+// k_small: S <= 8, one board per lane.  TFIX in 1..8: n_tiles == n_targets == TFIX, positions
 // live in registers; TFIX == 0: any tile count, positions staged in LDS.
 // ------------------------------------------------------------------------------------------
 #define TS_SMALL_THREADS (TS_WAVES_PER_BLOCK * 64 > 256 ? TS_WAVES_PER_BLOCK * 64 : 256)
@@ -1014,6 +1017,14 @@ SmallKernel small_kernel(int S, int tfix) {
     case 2: return small_kernel_for<2, EXTRAS>(S);
     case 3: return small_kernel_for<3, EXTRAS>(S);
     case 4: return small_kernel_for<4, EXTRAS>(S);
+#if TS_MAX_TFIX >= 6
+    case 5: return small_kernel_for<5, EXTRAS>(S);
+    case 6: return small_kernel_for<6, EXTRAS>(S);
+#endif
+#if TS_MAX_TFIX >= 8
+    case 7: return small_kernel_for<7, EXTRAS>(S);
+    case 8: return small_kernel_for<8, EXTRAS>(S);
+#endif
     default: return small_kernel_for<0, EXTRAS>(S);
   }
 }
@@ -1065,7 +1076,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   hipStream_t hs = (hipStream_t)stream;
 
   if (S <= 8) {
-    const int tfix = (T == Tt && T >= 1 && T <= 4 && T <= C) ? T : 0;  // cells in registers
+    const int tfix = (T == Tt && T >= 1 && T <= TS_MAX_TFIX && T <= C) ? T : 0;  // cells in registers
     if (a.onehot) {  // largest power-of-two chunk of boards whose one-hot byte image fits 16 KiB
       for (uint32_t nbc = kWave; nbc >= 4 && !a.oh_boards; nbc >>= 1)
         if (align16(nbc * (uint32_t)(a.onehot_ch * C)) <= 16u * 1024u) a.oh_boards = nbc;
