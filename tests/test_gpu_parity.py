@@ -304,12 +304,7 @@ def test_gym_wrapper_and_hipgraph_replay(torch_cuda, oracle):
     env.reset()
     ref.reset()
     torch.cuda.synchronize()
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
-            for a in acts:
-                env.step_async(a)
+    graph = env.capture_steps(acts)
     env.reset()
     for rep in range(2):
         graph.replay()

@@ -234,6 +234,31 @@ class VecTilerSliderEnv:
         self._call("ts_step", C.byref(self._dims), C.byref(self._state), a.data_ptr(), self._mode,
                    C.byref(self._out))
 
+    def capture_steps(self, action_buffers):
+        """Capture one ts_step per action buffer (uint8 device tensors [N], read at replay time)
+        into a hipGraph and return it; `graph.replay()` then runs the whole sequence with one
+        host call.  For small batches, where a step is shorter than a kernel launch from Python
+        (4096 4x4 boards: ~5 us of kernel per ~8 us of launch), this removes the host from the
+        loop; large batches are not launch-bound and gain nothing."""
+        self._require_open()
+        if self.host_mapped:
+            raise ValueError("capture_steps needs device buffers (host_mapped=False)")
+        bufs = [b for b in action_buffers]
+        for b in bufs:
+            if not (isinstance(b, torch.Tensor) and b.dtype == torch.uint8 and b.device == self.device
+                    and b.shape == (self.num_envs,) and b.is_contiguous()):
+                raise TypeError("action buffers must be contiguous uint8 device tensors of shape [N]")
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for b in bufs:
+                    self.step_async(b)
+        graph._ts_action_buffers = bufs  # keep the captured pointers alive
+        self._started = True
+        return graph
+
     def get_valid_moves(self):
         """bool [N, 4]: column d is True where Move(d) would change the board."""
         self._require_open()
