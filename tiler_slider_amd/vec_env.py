@@ -179,20 +179,24 @@ class VecTilerSliderEnv:
         self._closed = False
 
     # buffers live on the GPU, or (host_mapped) in pinned host memory the GPU addresses directly
+    def _pin(self, t):
+        if not t.numel() or t.is_pinned():
+            return t
+        with torch.cuda.device(self.device):  # pin in the context of the GPU that will use it
+            return t.pin_memory()
+
     def _zeros(self, shape, dtype):
         if self.host_mapped:
-            t = torch.zeros(shape, dtype=dtype)
-            return t.pin_memory() if t.numel() else t
+            return self._pin(torch.zeros(shape, dtype=dtype))
         return torch.zeros(shape, dtype=dtype, device=self.device)
 
     def _empty(self, shape, dtype):
         if self.host_mapped:
-            t = torch.empty(shape, dtype=dtype)
-            return t.pin_memory() if t.numel() else t
+            return self._pin(torch.empty(shape, dtype=dtype))
         return torch.empty(shape, dtype=dtype, device=self.device)
 
     def _place(self, t):
-        return t.pin_memory() if self.host_mapped and t.numel() and not t.is_pinned() else t
+        return self._pin(t) if self.host_mapped else t
 
     def _sync_if_host(self):
         if self.host_mapped:
