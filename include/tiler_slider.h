@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 2
+#define TS_ABI_VERSION 3
 #define TS_MAX_SIZE 32   /* cell ids: uint8 up to 16x16, uint16 up to 32x32 (ts_cell_bytes) */
 #define TS_MAX_TILES 255 /* observation stores tile index + 1 in one byte */
 
@@ -98,6 +98,9 @@ typedef struct ts_state {
   const uint32_t *blk; /* [W][N]  is_blocked bitmask (level) */
   int32_t *step_count; /* [N] */
   uint8_t *done;       /* [N] */
+  const uint32_t *lines; /* [N][ts_lines_words(S)] optional (ABI v3): the level's line masks built by
+                            ts_prepare.  NULL = the kernels derive them from blk / tgt on every
+                            call (slower above 8x8; results identical). */
 } ts_state;
 
 typedef struct ts_step_out {
@@ -174,6 +177,22 @@ int32_t ts_expand_u8(const uint8_t *src, float *dst, int64_t count, void *stream
  *            single colour: -sum_i min_j manhattan(tile_i, target_j) (0 if Tt == 0). */
 int32_t ts_encode_onehot(const ts_dims *dims, const ts_state *st, float *onehot, void *stream);
 int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void *stream);
+
+/* --- per-level tables (ABI v3) --------------------------------------------------
+ * A level's obstacles and targets never change during an episode, so everything the
+ * transition derives from them alone is computed once, by ts_prepare, into `lines`
+ * (ts_lines_words(S) uint32 words per board, board-major; 0 words for S <= 8, where the
+ * whole board lives in one register).  It is the reference's _precompute_moves idea
+ * (state.py:75-118: a per-level table built in the constructor) in the form the large-board
+ * kernel consumes.  Record of one board, Br[r] / Bc[c] = obstacles of row r / column c
+ * (bit i = i-th cell along the line), Tm[r] = target cells of row r:
+ *   S <= 16 (32 words): w[j] = Br[j] | Bc[j] << 16, w[16 + j] = Tm[j] (j < 16);
+ *                       bit 31 of w[16] set <=> two targets share a cell
+ *   S  > 16 (128 words): w[j] = Br[j], w[32 + j] = Bc[j], w[64 + j] = Tm[j] (j < 32);
+ *                       bit 0 of w[96] set <=> two targets share a cell; the rest 0
+ * Call ts_prepare again whenever blk or tgt change.  Reads st->blk and st->tgt only. */
+int32_t ts_lines_words(int32_t size);
+int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, void *stream);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */
 

@@ -75,6 +75,17 @@ def test_gamestate_adapter_matches_reference_golden(torch_cuda, name):
         assert st.current_locations == [tuple(map(int, x)) for x in g["pos"][b, -1]]  # copy is independent
 
 
+def _assert_plain_step(plain, act, ref, want, ctx=""):
+    """One step of an environment built WITHOUT optional outputs against the oracle state `ref`
+    (already stepped) and its outputs `want`."""
+    obs, done, info = plain.step(act)
+    np.testing.assert_array_equal(plain.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64), err_msg=ctx)
+    np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+    np.testing.assert_array_equal(plain.step_count.cpu().numpy(), ref.step_count, err_msg=ctx)
+    np.testing.assert_array_equal(done.cpu().numpy(), ref.done != 0, err_msg=ctx)
+    np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"], err_msg=ctx)
+
+
 # (S, T, K, multi_color, N, max_steps): ragged N (not a multiple of 64 / of 4), every kernel variant
 RANDOM_SHAPES = [
     (1, 1, 0, False, 67, 5), (2, 1, 1, True, 130, 7), (3, 1, 0, False, 1027, 9), (3, 2, 2, True, 513, 9),
@@ -109,7 +120,12 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps,
                                         auto_reset=autoreset, with_reward=True, with_onehot=True,
                                         with_valid_moves=True)
-    np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset())
+    # the same levels without the optional outputs: the plain kernels (k_small<EXTRAS = false>,
+    # and k_lines from 9x9 on, which works from the per-level tables of ts_prepare)
+    plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps, auto_reset=autoreset)
+    want0 = ref.reset()
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
+    np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
     mode = oracle.MODE_AUTORESET if autoreset else oracle.MODE_STRICT
     for step in range(24):
         act = oracle.fill_actions(N, seed=77 + S, step_index=step)
@@ -118,6 +134,7 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
         obs, done, info = env.step(torch.from_numpy(act))
         want = ref.step(act, mode=mode, reward=True, onehot=True, valid=True)
         ctx = f"S={S} T={T} step={step}"
+        _assert_plain_step(plain, torch.from_numpy(act), ref, want, ctx)
         np.testing.assert_array_equal(env.positions.cpu().numpy(), ref.pos, err_msg=ctx)
         np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
         np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref.step_count, err_msg=ctx)
@@ -134,6 +151,8 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     np.testing.assert_array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
     np.testing.assert_array_equal(env.reward().cpu().numpy(), ref.reward())
     np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
+    np.testing.assert_array_equal(plain.encode().cpu().numpy(), ref.encode())
+    np.testing.assert_array_equal(plain.is_won().cpu().numpy(), ref.won() != 0)
     if not autoreset and max_steps < 24:  # strict mode: every board timed out and was then flagged
         assert (ref.done != 0).all()
 
@@ -150,11 +169,15 @@ def test_mismatched_tile_and_target_counts(torch_cuda, oracle):
         ref = oracle.OracleBatch(S, mc, 50, blk, init, tgt)
         env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=50, with_reward=True,
                                             with_onehot=True)
-        np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset())
+        plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=50)
+        want0 = ref.reset()
+        np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
+        np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
         for step in range(6):
             act = oracle.fill_actions(N, seed=8, step_index=step)
             obs, done, info = env.step(torch.from_numpy(act))
             want = ref.step(act, reward=True, onehot=True)
+            _assert_plain_step(plain, torch.from_numpy(act), ref, want, f"S={S} T={T} Tt={Tt}")
             np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"])
             np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"])
             np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"])
@@ -338,13 +361,17 @@ def test_fuzzed_shapes_vs_oracle(torch_cuda, oracle):
         env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps,
                                             auto_reset=autoreset, with_reward=True, with_valid_moves=True,
                                             with_onehot=C * (1 + T + Tt) <= 20000)
+        plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps, auto_reset=autoreset)
         ctx = f"case={case} S={S} T={T} Tt={Tt} K={K} mc={mc} autoreset={autoreset} N={N}"
-        np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset(), err_msg=ctx)
+        want0 = ref.reset()
+        np.testing.assert_array_equal(env.reset().cpu().numpy(), want0, err_msg=ctx)
+        np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0, err_msg=ctx)
         mode = oracle.MODE_AUTORESET if autoreset else oracle.MODE_STRICT
         for step in range(6):
             act = oracle.fill_actions(N, seed=300 + case, step_index=step)
             obs, done, info = env.step(torch.from_numpy(act))
             want = ref.step(act, mode=mode, reward=True, valid=True, onehot=env._onehot is not None)
+            _assert_plain_step(plain, torch.from_numpy(act), ref, want, ctx)
             np.testing.assert_array_equal(env.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64), err_msg=ctx)
             np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
             np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref.step_count, err_msg=ctx)
@@ -376,11 +403,18 @@ def test_large_batches_vs_oracle(torch_cuda, oracle, S, T, K, mc, N):
     ref = oracle.OracleBatch(S, mc, 2**30, blk, init, tgt)
     env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=2**30, auto_reset=True,
                                         with_reward=True, with_valid_moves=True)
-    assert np.array_equal(env.reset().cpu().numpy(), ref.reset())
+    plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=2**30, auto_reset=True)
+    want0 = ref.reset()
+    assert np.array_equal(env.reset().cpu().numpy(), want0)
+    assert np.array_equal(plain.reset().cpu().numpy(), want0)
     for step in range(3):
         act = oracle.fill_actions(N, seed=99, step_index=step)
         obs, done, info = env.step(torch.from_numpy(act))
         want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True, valid=True)
+        pobs, pdone, pinfo = plain.step(torch.from_numpy(act))
+        assert np.array_equal(plain.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64))
+        assert np.array_equal(pinfo["flags"].cpu().numpy(), want["flags"])
+        assert np.array_equal(pobs.cpu().numpy(), want["obs"])
         assert np.array_equal(env.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64))
         assert np.array_equal(info["flags"].cpu().numpy(), want["flags"])
         assert np.array_equal(obs.cpu().numpy(), want["obs"])
@@ -456,3 +490,68 @@ def test_expand_u8(torch_cuda):
         assert torch.equal(dst[:count], src[:count].to(torch.float32))
         assert bool((dst[count:] == -1.0).all())  # nothing past the end is touched
     assert L.ts_expand_u8(None, None, 8, st) == _cabi.ERR_NULL and L.ts_expand_u8(None, None, -1, st) == _cabi.ERR_DIMS
+
+
+def _lines_record_numpy(S, blk, tgt):
+    """The ts_prepare record (include/tiler_slider.h) restated with numpy, board by board."""
+    N = blk.shape[1]
+    C = S * S
+    wide = S > 16
+    rec = np.zeros((N, 128 if wide else 32), np.uint32)
+    for n in range(N):
+        grid = np.array([(int(blk[p >> 5, n]) >> (p & 31)) & 1 for p in range(C)], np.uint32).reshape(S, S)
+        br = [int(sum(int(grid[r, c]) << c for c in range(S))) for r in range(S)]
+        bc = [int(sum(int(grid[r, c]) << r for r in range(S))) for c in range(S)]
+        cells = [min(int(x), C - 1) for x in tgt[:, n]]
+        tm = [0] * S
+        for x in cells:
+            tm[x // S] |= 1 << (x % S)
+        dup = int(len(set(cells)) != len(cells))
+        for j in range(S):
+            if wide:
+                rec[n, j], rec[n, 32 + j], rec[n, 64 + j] = br[j], bc[j], tm[j]
+            else:
+                rec[n, j] = br[j] | (bc[j] << 16)
+                rec[n, 16 + j] = tm[j]
+        if wide:
+            rec[n, 96] = dup
+        else:
+            rec[n, 16] |= dup << 31
+    return rec
+
+
+@pytest.mark.parametrize("S,T,Tt,K,N", [(9, 4, 4, 9, 37), (12, 8, 3, 30, 21), (15, 32, 32, 24, 50), (16, 40, 40, 100, 13),
+                                        (17, 3, 5, 20, 9), (24, 30, 30, 60, 6), (32, 64, 64, 300, 5)])
+def test_prepare_tables_match_numpy(torch_cuda, oracle, S, T, Tt, K, N):
+    """ts_prepare (the per-level line masks k_lines consumes) against a numpy restatement of the
+    record documented in include/tiler_slider.h, with and without duplicate target cells."""
+    from tiler_slider_amd import VecTilerSliderEnv
+    blk, init, _ = oracle.generate(S, T, 0, K, N, seed=11)
+    _, _, tgt = oracle.generate(S, 0, Tt, 0, N, seed=12)
+    if Tt >= 2:
+        tgt[1, ::3] = tgt[0, ::3]  # every third board has two targets on one cell
+    env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=True)
+    got = env._lines.cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got, _lines_record_numpy(S, blk, tgt))
+
+
+@pytest.mark.parametrize("S,T,K,mc,N", [(9, 4, 9, True, 1001), (15, 32, 24, True, 515), (15, 32, 24, False, 515),
+                                        (16, 17, 30, False, 130), (20, 6, 30, True, 67), (32, 64, 100, False, 35)])
+def test_without_tables_equals_with_tables(torch_cuda, oracle, S, T, K, mc, N):
+    """ts_state.lines = NULL (callers that never ran ts_prepare: k_large derives everything per
+    step) and the table-driven k_lines give the same boards, flags and observations."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=21)
+    tgt[1 if T > 1 else 0, ::5] = tgt[0, ::5]
+    a = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True)
+    b = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True)
+    b._state.lines = None
+    assert torch.equal(a.reset(), b.reset())
+    for step in range(12):
+        act = torch.from_numpy(oracle.fill_actions(N, seed=4, step_index=step))
+        oa, da, ia = a.step(act)
+        ob, db, ib = b.step(act)
+        assert torch.equal(oa, ob) and torch.equal(da, db) and torch.equal(ia["flags"], ib["flags"])
+        assert torch.equal(a.positions, b.positions) and torch.equal(a.step_count, b.step_count)
+    assert torch.equal(a.is_won(), b.is_won()) and torch.equal(a.encode(), b.encode())

@@ -15,7 +15,7 @@ SRC = os.path.join(_PKG, "csrc", "ts_kernels.hip")
 HEADERS = [os.path.join(_PKG, "csrc", "ts_core.h"), os.path.join(ROOT, "include", "tiler_slider.h")]
 LIB_PATH = os.path.join(_PKG, "lib", "libtiler_slider_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 OK, ERR_NULL, ERR_DIMS, ERR_LIMIT, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0x08
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
@@ -23,7 +23,8 @@ MODE_STRICT, MODE_AUTORESET = 0, 1
 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
-           "ts_encode_u8", "ts_expand_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions")
+           "ts_encode_u8", "ts_expand_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions",
+           "ts_lines_words", "ts_prepare")
 
 
 class Dims(C.Structure):
@@ -33,7 +34,7 @@ class Dims(C.Structure):
 
 class State(C.Structure):
     _fields_ = [("pos", C.c_void_p), ("init", C.c_void_p), ("tgt", C.c_void_p), ("blk", C.c_void_p),
-                ("step_count", C.c_void_p), ("done", C.c_void_p)]
+                ("step_count", C.c_void_p), ("done", C.c_void_p), ("lines", C.c_void_p)]
 
 
 class StepOut(C.Structure):
@@ -101,13 +102,15 @@ def lib():
     L.ts_blk_words.restype = C.c_int32
     L.ts_cell_bytes.argtypes = [C.c_int32]
     L.ts_cell_bytes.restype = C.c_int32
+    L.ts_lines_words.argtypes = [C.c_int32]
+    L.ts_lines_words.restype = C.c_int32
     L.ts_onehot_channels.argtypes = [DP]
     L.ts_onehot_channels.restype = C.c_int32
     L.ts_check_dims.argtypes = [DP]
     L.ts_check_dims.restype = C.c_int32
     for name, args in (("ts_reset", [DP, SP, P, P]),
                        ("ts_step", [DP, SP, P, C.c_uint32, C.POINTER(StepOut), P]),
-                       ("ts_valid_moves", [DP, SP, P, P]), ("ts_is_won", [DP, SP, P, P]),
+                       ("ts_valid_moves", [DP, SP, P, P]), ("ts_is_won", [DP, SP, P, P]), ("ts_prepare", [DP, SP, P, P]),
                        ("ts_encode", [DP, SP, P, P]), ("ts_encode_u8", [DP, SP, P, P]),
                        ("ts_encode_onehot", [DP, SP, P, P]), ("ts_reward", [DP, SP, P, P]),
                        ("ts_generate", [DP, SP, C.c_uint64, C.c_int64, C.c_int32, P]),

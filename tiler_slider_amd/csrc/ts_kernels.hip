@@ -56,6 +56,21 @@
 #ifndef TS_WAVES_PER_BLOCK
 #define TS_WAVES_PER_BLOCK 4
 #endif
+#ifndef TS_USE_LINES  // 0 = ignore ts_state.lines (always k_large above 8x8): A/B against round 1's kernel
+#define TS_USE_LINES 1
+#endif
+#ifndef TS_LINES_LDS_PAD  // diagnostic: extra dynamic LDS per wave of k_lines (lowers the resident waves)
+#define TS_LINES_LDS_PAD 0
+#endif
+#ifndef TS_FORCE_OBS_BOARDS  // diagnostic: 64 = round 1's one-pass observation image at every size
+#define TS_FORCE_OBS_BOARDS 0
+#endif
+#ifndef TS_MAX_BLOCK_LDS  // dynamic LDS a block may ask for (bytes)
+#define TS_MAX_BLOCK_LDS (60 * 1024)
+#endif
+#ifndef TS_SET_LDS_ATTR  // diagnostic: hipFuncSetAttribute(MaxDynamicSharedMemorySize) before k_small launches
+#define TS_SET_LDS_ATTR 0
+#endif
 
 namespace {
 
@@ -77,6 +92,7 @@ struct KArgs {
   float *onehot;
   uint8_t *valid;
   uint8_t *obs_u8;
+  const uint32_t *lines;  // per-level line masks (ts_prepare), or null
   int64_t N;
   int32_t T, Tt, mc, max_steps;
   uint32_t op, autoreset;
@@ -196,7 +212,7 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
 }
 
 // boards per observation pass of k_small (also used by the host to size the LDS carve)
-constexpr int small_obs_boards(int C) { return kWave * 3 * C <= 6144 ? kWave : kWave / 2; }
+constexpr int small_obs_boards(int C) { return TS_FORCE_OBS_BOARDS ? TS_FORCE_OBS_BOARDS : (kWave * 3 * C <= 6144 ? kWave : kWave / 2); }
 
 constexpr int kSmallBatch = 8;  // global loads in flight per lane in the any-T tile / target loops
 
@@ -921,6 +937,319 @@ __global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// k_lines<WIDE, TPL>: the plain step / reset / encode path for S in 9..32 when the caller hands
+// in the level's precomputed line masks (ts_state.lines, built once per level by ts_prepare).
+//
+// k_large re-derives everything that never changes during an episode on every step: it unpacks
+// the packed obstacle words row by row, transposes them into column masks with per-bit LDS
+// atomics, rebuilds the target row masks and reads the target bytes back to look for duplicate
+// target cells — 45.6 M vector instructions per cfg4 launch, 78 us of issue-bound work that did
+// not hide behind the 120 us of observation stores (profiles/r01_sq_counters.md).  Here those
+// tables are plain loads:
+//   * 16 lanes per board (4 boards per wave); lane j owns line j (and j + 16 above 16x16) and
+//     loads that line's obstacle masks  — one coalesced 4-B load per lane up to 16x16;
+//   * tiles live in registers (tile t -> lane t mod 16, TPL = tiles per lane is a template
+//     constant, so the tile loops are fully unrolled and their loads go out together);
+//   * per-step LDS work: one atomic OR per tile for the occupancy of the lines the move runs
+//     along, one read of the tile's own line; post-move row masks only for the set-equality win
+//     test of single-colour boards;
+//   * duplicate target cells are a property of the level: ts_prepare flags them, and only
+//     flagged boards pay for the "highest index wins" fix-up (state.py:209-211).
+// The legality mask, the reward and the one-hot planes stay with k_large (EXTRAS launches).
+// ------------------------------------------------------------------------------------------
+constexpr int kLinesG = 16;                   // lanes per board
+constexpr int kLinesBPW = kWave / kLinesG;    // boards per wave
+constexpr int lines_record_words(bool wide) { return wide ? 128 : 32; }
+// Record of one board in ts_state.lines (uint32 words; include/tiler_slider.h):
+//   S <= 16: w[j] = Br[j] | Bc[j] << 16 (j < 16)     w[16 + j] = Tm[j]     bit 31 of w[16]: duplicate targets
+//   S  > 16: w[j] = Br[j], w[32 + j] = Bc[j], w[64 + j] = Tm[j] (j < 32)   bit 0 of w[96]: duplicate targets
+// Br[r] / Bc[c]: obstacles of row r / column c (bit i = i-th cell along the line); Tm[r]: targets of row r.
+
+template <bool WIDE, int TPL>
+__global__ __launch_bounds__(256) void k_lines(const KArgs a, const int S, const uint32_t invS) {
+  using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
+  constexpr int G = kLinesG, BPW = kLinesBPW;
+  constexpr int R = WIDE ? 2 : 1;   // lines per lane
+  constexpr int NL = G * R;         // line slots of one board in LDS
+  constexpr int REC = lines_record_words(WIDE);
+  auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
+  auto mul_s = [&](int x) -> int { return (int)__umul24((uint32_t)x, (uint32_t)S); };
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int g = lane >> 4, j = lane & (G - 1);
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * BPW;
+  if (n0 >= a.N) return;  // wave-uniform
+  const int64_t N = a.N;
+  const int64_t n = n0 + g;
+  const bool live = n < N;
+  const int64_t nl = live ? n : N - 1;  // lanes past the batch read the last board and write nothing:
+                                        // every load below is unconditional, so all of them are in
+                                        // flight before the first one is waited for
+  const int nb = (N - n0) < BPW ? (int)(N - n0) : BPW;
+  const int C = S * S;
+  const int T = a.T, Tt = a.Tt;
+  const bool mc = a.mc != 0;
+  const uint64_t gmask = 0xffffull << (g * G);
+
+  unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;          // [BPW][3C] bytes, flat
+  uint32_t *lnB = reinterpret_cast<uint32_t *>(img + a.lds_stage_off);  // obstacle line masks [BPW][NL] (x2 when WIDE)
+  uint32_t *occ = lnB + BPW * NL * R;                                   // pre-move tiles along the move's lines
+  uint32_t *nrw = occ + BPW * NL;                                       // post-move tiles by row (single colour only)
+  const int lb = g * NL;
+
+  // ---- loads ----
+  const uint32_t *rec = a.lines + (size_t)nl * REC;
+  uint32_t wB[R * R], wx[R];  // wx: target row masks (single colour) or the duplicate-target word (multi colour)
+  if constexpr (WIDE) {
+    wB[0] = rec[j];
+    wB[1] = rec[j + 16];
+    wB[2] = rec[32 + j];
+    wB[3] = rec[48 + j];
+    wx[0] = rec[mc ? 96 : 64 + j];
+    wx[1] = rec[mc ? 96 : 80 + j];
+  } else {
+    wB[0] = rec[j];
+    wx[0] = rec[mc ? 16 : 16 + j];
+  }
+  const cell_t *g_pos = reinterpret_cast<const cell_t *>(a.pos);
+  const cell_t *g_init = reinterpret_cast<const cell_t *>(a.init);
+  const cell_t *g_tgt = reinterpret_cast<const cell_t *>(a.tgt);
+  const int64_t off0 = (int64_t)j * N + nl;  // row j of an SoA array, this board
+  const int64_t gs = (int64_t)G * N;         // G rows further
+  const bool all_reset = a.op == OP_RESET;
+  int p[TPL], tg[TPL];
+  bool hasT[TPL], hasG[TPL];
+#pragma unroll
+  for (int k = 0; k < TPL; ++k) {
+    hasT[k] = j + k * G < T;
+    hasG[k] = j + k * G < Tt;
+    // rows past the tile count read row 0 of this board (in range whenever the branch is taken)
+    p[k] = (T > 0 && !all_reset) ? (int)g_pos[hasT[k] ? off0 + k * gs : nl] : 0;
+    tg[k] = Tt > 0 ? (int)g_tgt[hasG[k] ? off0 + k * gs : nl] : 0;
+  }
+  uint32_t action = 0, done_in = 0;
+  int32_t sc = 0;
+  if (a.op == OP_STEP) {  // uniform
+    done_in = a.done[nl];
+    sc = a.step_count[nl];
+    action = a.actions[nl];
+  }
+
+  // ---- LDS: line masks in, occupancy cleared, image zero-filled (no loaded value needed yet
+  //      except the line masks) ----
+  const bool want_obs = a.obs != nullptr || a.obs_u8 != nullptr;
+  if (want_obs) {
+    const int img_bytes = (BPW * 3 * C + 15) & ~15;
+    for (int off = lane * 16; off < img_bytes; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    occ[lb + j + i * G] = 0u;
+    nrw[lb + j + i * G] = 0u;
+    lnB[lb * R + j + i * G] = wB[i];
+    if constexpr (WIDE) lnB[lb * R + NL + j + i * G] = wB[2 + i];
+  }
+
+  int kind;  // 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells
+  uint32_t flags = 0;
+  if (a.op == OP_RESET) {
+    kind = 2;
+  } else if (a.op == OP_OBSERVE) {
+    kind = 1;
+  } else {
+    // environment.py:113-117: done boards are not stepped, action bytes above 3 are refused
+    kind = done_in ? (a.autoreset ? 2 : 1) : (action > 3 ? 1 : 0);
+    flags = done_in ? (a.autoreset ? TS_FLAG_AUTORESET : TS_FLAG_STEPPED_DONE) : (action > 3 ? TS_FLAG_BAD_ACTION : 0u);
+  }
+  const bool slide = kind == 0;
+  const bool vert = (action & 2u) == 0, neg = (action & 1u) == 0;
+  if (kind == 2 && !all_reset) {  // boards that autoreset inside a step: rare
+#pragma unroll
+    for (int k = 0; k < TPL; ++k)
+      if (hasT[k]) p[k] = (int)g_init[off0 + k * gs];
+  } else if (all_reset && T > 0) {  // ts_reset: uniform
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) p[k] = (int)g_init[hasT[k] ? off0 + k * gs : nl];
+  }
+  wave_sync();
+
+  // ---- pre-move occupancy of the lines the move runs along (state.py:137-144 sorts by them) ----
+  int pr[TPL], pc[TPL];
+#pragma unroll
+  for (int k = 0; k < TPL; ++k) {
+    p[k] = min(p[k], C - 1);  // clamp: malformed ids stay in-board
+    tg[k] = min(tg[k], C - 1);
+    pr[k] = div_s(p[k]);
+    pc[k] = p[k] - mul_s(pr[k]);
+    // boards that do not slide and rows past the tile count OR in a zero: no branch
+    atomicOr(&occ[lb + (vert ? pc[k] : pr[k])], (slide && hasT[k]) ? 1u << (vert ? pr[k] : pc[k]) : 0u);
+  }
+  wave_sync();
+
+  // ---- slide (state.py:120-170) ----
+  bool same = true, ordered = true;
+  cell_t *pos_out = reinterpret_cast<cell_t *>(a.pos) + off0;
+  const bool store_pos = live && kind != 1;
+#pragma unroll
+  for (int k = 0; k < TPL; ++k) {
+    const int line = vert ? pc[k] : pr[k];
+    const uint32_t O = occ[lb + line];
+    uint32_t B;
+    if constexpr (WIDE) {
+      B = lnB[lb * R + (vert ? NL : 0) + line];
+    } else {
+      const uint32_t w = lnB[lb + line];
+      B = vert ? (w >> 16) : (w & 0xffffu);
+    }
+    const int x0 = vert ? pr[k] : pc[k];
+    const int x1 = ts::slide_line(x0, B, O, S, neg);
+    const int x = slide ? x1 : x0;
+    const int r = vert ? x : pr[k], c = vert ? pc[k] : x;
+    const int q = mul_s(r) + c;
+    same &= (q == p[k]) | !hasT[k];
+    ordered &= (q == tg[k]) | !(hasT[k] && hasG[k]);
+    if (!mc) atomicOr(&nrw[lb + r], hasT[k] ? 1u << c : 0u);
+    if (store_pos && hasT[k]) pos_out[k * gs] = (cell_t)q;
+    p[k] = q;
+  }
+  bool rows_equal = true;
+  if (!mc) {
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < R; ++i) rows_equal &= nrw[lb + j + i * G] == (WIDE ? wx[i] : (wx[i] & 0xffffu));
+  }
+  const bool all_same = (__ballot(same) & gmask) == gmask;
+  const bool all_ordered = (T == Tt) && ((__ballot(ordered) & gmask) == gmask);
+  const bool all_rows = (__ballot(rows_equal) & gmask) == gmask;
+
+  const bool won = mc ? all_ordered : all_rows;  // state.py:172-186
+  if (a.op == OP_OBSERVE && won) flags |= TS_FLAG_IS_WON;
+  if (slide) {
+    if (won) flags |= TS_FLAG_IS_WON | TS_FLAG_SUCCESS;
+    if (all_same) flags |= TS_FLAG_INVALID_MOVE;
+    sc += 1;
+    if (sc >= a.max_steps) flags |= TS_FLAG_TIMEOUT;
+  }
+  if (live && j == 0) {
+    if (slide) {
+      a.step_count[n] = sc;
+      a.done[n] = (uint8_t)((flags & (TS_FLAG_IS_WON | TS_FLAG_TIMEOUT)) != 0);
+    } else if (kind == 2) {
+      a.step_count[n] = 0;
+      a.done[n] = 0;
+    }
+    if (a.flags) a.flags[n] = (uint8_t)flags;
+  }
+
+  // ---- observation (state.py:188-211) through the LDS byte image ----
+  if (want_obs) {
+    unsigned char *my = img + g * (3 * C);
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        unsigned char *myrow = my + 3 * mul_s(j + i * G);
+        for (uint32_t m = WIDE ? wB[i] : (wB[0] & 0xffffu); m; m &= m - 1) myrow[3 * ts::lsb(m)] = 1;
+      }
+#pragma unroll
+      for (int k = 0; k < TPL; ++k)
+        if (hasT[k]) my[3 * p[k] + 1] = (unsigned char)(mc ? j + k * G + 1 : 1);
+#pragma unroll
+      for (int k = 0; k < TPL; ++k)
+        if (hasG[k]) my[3 * tg[k] + 2] = (unsigned char)(mc ? j + k * G + 1 : 1);
+    }
+    const bool dup = mc && live && (WIDE ? (wx[0] & 1u) != 0 : (wx[0] >> 31) != 0);
+    if (__ballot(dup) != 0) {
+      // Duplicate target cells (never from the factories): the highest index must win
+      // (state.py:209-211), which lanes writing in parallel cannot promise.  Every lane of a
+      // flagged board raises its targets' bytes until none is below its own index + 1; each
+      // round strictly increases at least one byte, so the loop ends.
+      for (;;) {
+        wave_sync();
+        bool again = false;
+        if (dup) {
+#pragma unroll
+          for (int k = 0; k < TPL; ++k) {
+            const int t = j + k * G;
+            if (hasG[k] && my[3 * tg[k] + 2] < (unsigned char)(t + 1)) {
+              my[3 * tg[k] + 2] = (unsigned char)(t + 1);
+              again = true;
+            }
+          }
+        }
+        if (__ballot(again) == 0) break;
+      }
+    }
+    wave_sync();
+    if (a.obs) emit_bytes_as_f32(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.nt != 0);
+    if (a.obs_u8) emit_bytes_raw<4>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
+  }
+}
+
+// ts_prepare: the static tables of k_lines, once per level.  Same lane mapping as k_lines (16 lanes
+// per board, lane j builds line j and j + 16); not a hot path.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_prepare(const uint32_t *blk, const void *tgt_v, uint32_t *lines, int64_t N, int S, int Tt) {
+  using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
+  constexpr int R = WIDE ? 2 : 1;
+  constexpr int REC = lines_record_words(WIDE);
+  const cell_t *tgt = reinterpret_cast<const cell_t *>(tgt_v);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int g = lane >> 4, j = lane & 15;
+  const int64_t n = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kLinesBPW + g;
+  const bool live = n < N;
+  const int C = S * S;
+  const uint64_t gmask = 0xffffull << (g * 16);
+  uint32_t br[R], bc[R], tm[R], cnt[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) br[i] = bc[i] = tm[i] = cnt[i] = 0;
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int line = j + i * 16;
+      if (line < S) {
+        for (int x = 0; x < S; ++x) {
+          const int pr_ = line * S + x, pc_ = x * S + line;  // cell x of row `line` / of column `line`
+          br[i] |= ((blk[(int64_t)(pr_ >> 5) * N + n] >> (pr_ & 31)) & 1u) << x;
+          bc[i] |= ((blk[(int64_t)(pc_ >> 5) * N + n] >> (pc_ & 31)) & 1u) << x;
+        }
+      }
+    }
+    for (int t = 0; t < Tt; ++t) {
+      int cell = (int)tgt[(int64_t)t * N + n];
+      cell = cell < C - 1 ? cell : C - 1;
+      const int r = cell / S, c = cell - r * S;
+#pragma unroll
+      for (int i = 0; i < R; ++i)
+        if (r == j + i * 16) {
+          tm[i] |= 1u << c;
+          cnt[i] += 1;
+        }
+    }
+  }
+  bool dup_here = false;  // more targets in my rows than distinct target cells
+#pragma unroll
+  for (int i = 0; i < R; ++i) dup_here |= cnt[i] != (uint32_t)__builtin_popcount(tm[i]);
+  const uint32_t dup = (__ballot(dup_here) & gmask) != 0 ? 1u : 0u;
+  if (!live) return;
+  uint32_t *rec = lines + (size_t)n * REC;
+  if constexpr (WIDE) {
+    rec[j] = br[0];
+    rec[j + 16] = br[1];
+    rec[32 + j] = bc[0];
+    rec[48 + j] = bc[1];
+    rec[64 + j] = tm[0];
+    rec[80 + j] = tm[1];
+    rec[96 + j] = j == 0 ? dup : 0u;
+    rec[112 + j] = 0u;
+  } else {
+    rec[j] = br[0] | (bc[0] << 16);
+    rec[16 + j] = tm[0] | (j == 0 ? dup << 31 : 0u);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // Synthetic inputs
 // ------------------------------------------------------------------------------------------
@@ -1036,7 +1365,7 @@ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 // 8x8 / 20 tiles at >= 100k boards: 1..4 % of the boards wrong, none in the first blocks of each
 // CU) — consistent with the size wrapping to 0 in a 16-bit field.  Blocks shrink to 2 or 1
 // wave(s) instead; a single wave never needs more than ~36 KiB.
-constexpr size_t kMaxBlockLds = 60u * 1024u;
+constexpr size_t kMaxBlockLds = TS_MAX_BLOCK_LDS;
 
 int32_t finish_launch() {
   const hipError_t e = hipGetLastError();
@@ -1093,7 +1422,35 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
     const bool extras = a.valid || a.reward || a.onehot;
     SmallKernel k = extras ? small_kernel<true>(S, tfix) : small_kernel<false>(S, tfix);
+#if TS_SET_LDS_ATTR
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)waves * a.lds_wave_bytes));
+#endif
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a);
+  } else if (st->lines && !a.valid && !a.reward && !a.onehot && TS_USE_LINES) {
+    // plain step / reset / encode with the level's precomputed line masks: k_lines
+    const bool wide = S > 16;
+    a.lines = st->lines;
+    const int per_lane = ((T > Tt ? T : Tt) + kLinesG - 1) / kLinesG;
+    int tpl = 1;
+    while (tpl < per_lane) tpl <<= 1;
+    a.lds_stage_off = align16((uint32_t)(kLinesBPW * 3 * C));
+    a.lds_wave_bytes = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) + TS_LINES_LDS_PAD;
+    const int waves = 4;
+    if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
+    const int64_t boards_per_block = (int64_t)waves * kLinesBPW;
+    const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
+    if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
+    const uint32_t inv_s = (uint32_t)((65536 + S - 1) / S);
+    using LinesKernel = void (*)(const KArgs, const int, const uint32_t);
+    LinesKernel k = nullptr;
+    switch (tpl) {
+      case 1: k = wide ? k_lines<true, 1> : k_lines<false, 1>; break;
+      case 2: k = wide ? k_lines<true, 2> : k_lines<false, 2>; break;
+      case 4: k = wide ? k_lines<true, 4> : k_lines<false, 4>; break;
+      case 8: k = wide ? k_lines<true, 8> : k_lines<false, 8>; break;
+      default: k = wide ? k_lines<true, 16> : k_lines<false, 16>; break;
+    }
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, inv_s);
   } else {
     const bool wide = S > 16;
     const uint32_t mask_bytes = wide ? (uint32_t)sizeof(LineMasks<32>) : (uint32_t)sizeof(LineMasks<16>);
@@ -1281,6 +1638,24 @@ int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void
   a.op = OP_OBSERVE;
   a.reward = reward;
   return launch(dims, st, a, stream);
+}
+
+int32_t ts_lines_words(int32_t size) { return size < 9 || size > TS_MAX_SIZE ? 0 : lines_record_words(size > 16); }
+
+int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, void *stream) {
+  const int32_t rc = check_dims(dims);
+  if (rc) return rc;
+  if (dims->size < 9 || dims->n_boards == 0) return TS_OK;  // k_small needs no tables
+  if (!st || !st->blk || !lines || (dims->n_targets && !st->tgt)) return TS_ERR_NULL;
+  const int64_t blocks = (dims->n_boards + 4 * kLinesBPW - 1) / (4 * kLinesBPW);
+  if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
+  if (dims->size > 16)
+    hipLaunchKernelGGL(k_prepare<true>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, st->blk, st->tgt, lines,
+                       dims->n_boards, dims->size, dims->n_targets);
+  else
+    hipLaunchKernelGGL(k_prepare<false>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, st->blk, st->tgt, lines,
+                       dims->n_boards, dims->size, dims->n_targets);
+  return finish_launch();
 }
 
 int32_t ts_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int64_t board_offset, int32_t n_obstacles,

@@ -168,8 +168,15 @@ class VecTilerSliderEnv:
         self._onehot = (self._zeros((N, self.onehot_channels, self.size, self.size), torch.float32)
                         if with_onehot else None)
         self._valid = self._zeros(N, torch.uint8) if with_valid_moves else None
+        # per-level tables of the large-board kernel (include/tiler_slider.h: ts_prepare): the level
+        # never changes during an episode, so they are built once, here
+        lw = L.ts_lines_words(self.size)
+        self._lines = self._zeros((N, lw), torch.int32) if lw and N else None
         self._state = _cabi.State(_ptr(self._pos), _ptr(self._init), _ptr(self._tgt), _ptr(self._blk),
-                                  _ptr(self._step_count), _ptr(self._done))
+                                  _ptr(self._step_count), _ptr(self._done), None)
+        if self._lines is not None:
+            self._call("ts_prepare", C.byref(self._dims), C.byref(self._state), _ptr(self._lines))
+            self._state.lines = _ptr(self._lines)
         f32 = obs_dtype == torch.float32
         self._out = _cabi.StepOut(_ptr(self._flags), _ptr(self._obs) if f32 else None, _ptr(self._reward),
                                   _ptr(self._onehot), _ptr(self._valid), None if f32 else _ptr(self._obs))
