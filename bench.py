@@ -2,6 +2,7 @@
 """bench.py — env-steps/sec of the batched Tiler-Slider step() on MI355X.
 
     python bench.py --gpus 1 --steps 500 --warmup 50
+    python bench.py --gpus 8                      # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -11,7 +12,8 @@ done latch, float32 observation).  Workload = BASELINE.json configs[1]: 1,048,57
 actions, inputs resident in HBM before the timed region, autoreset so every board stays live.
 Boards shard across ranks with no data-path collective (weak scaling); the RCCL all-gather
 that hands observations to a single learner is timed separately and reported under
-"allgather".  Rank 0 prints ONE JSON line.
+"allgather" (serial, and overlapped with the next step on double-buffered observations).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -25,7 +27,9 @@ if ROOT not in sys.path:
 
 LEVEL_SEED = 0x715311DE
 ACTION_SEED = 0xAC710005
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guide: 6.29 TB/s is the measured copy ceiling)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+COPY_CEILING_GBS = 6290.0  # measured float4 copy ceiling (/opt/skills/guides/MI355X_MICROARCH.md, chip-level table)
+INFINITY_CACHE_BYTES = 256 << 20
 
 CONFIGS = {
     # name: (size, tiles, obstacles, boards per GPU, extras)
@@ -107,6 +111,25 @@ def cpu_baseline(cfg, budget_s=10.0):
                                                   "build container (BASELINE.md §2); the reference cannot travel"}}
 
 
+def spawn_ranks(n):
+    """`python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child
+    process; returns its exit code.  Fails with a message (no hang) when the box has fewer GPUs."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs on this node, found {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +140,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-sibling", action="store_true", help="skip the out-of-cache sibling of a cache-resident config")
     ap.add_argument("--compact-u8", action="store_true",
                     help="also time the opt-in uint8-observation variant (reported as compact_u8_obs; off by "
                          "default so that a profile of the default run contains only the headline launches)")
@@ -124,6 +148,12 @@ def main():
                     help="rehearsal: take the multi-rank code path (RCCL group, max-over-ranks reduction, "
                          "all-gather timings) even with one rank; launch under torch.distributed.run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves.  This process has not
+        # touched the GPU (torch.cuda.device_count() does not initialise it on ROCm); the ranks
+        # are fresh children, this process only relays their output and exit code.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -133,7 +163,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: they must agree")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     multi = world > 1 or args.force_dist
@@ -231,6 +261,38 @@ def main():
                    "algorithmic_bytes_per_board_step": b8, "achieved_GBps": b8 * n / us / 1e3}
         del env8
 
+    # the same kernel on a batch whose working set cannot stay in the Infinity Cache: the
+    # HBM-bound sibling of a cache-resident headline figure
+    sibling = None
+    bps_cfg = algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
+    if world == 1 and bps_cfg * n < INFINITY_CACHE_BYTES and not args.no_sibling:
+        n_big = 4 * n
+        big = VecTilerSliderEnv.random(n_big, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
+                                       seed=LEVEL_SEED, multi_color=True, max_steps=2**30, device=device, auto_reset=True,
+                                       with_reward=cfg["reward"], with_onehot=cfg["onehot"])
+        big.reset()
+        acts = []
+        for i in range(4):
+            a = torch.empty(n_big, dtype=torch.uint8, device=device)
+            _cabi.check(L.ts_fill_actions(n_big, ACTION_SEED, 0, i, a.data_ptr(), stream), "ts_fill_actions")
+            acts.append(a)
+        for i in range(10):
+            big.step_async(acts[i & 3])
+        k = min(args.steps, 100)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(k):
+            big.step_async(acts[i & 3])
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / k
+        gbs = bps_cfg * n_big / us / 1e3
+        sibling = {"boards": n_big, "kernel_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                   "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS, "algorithmic_bytes_per_launch": bps_cfg * n_big,
+                   "value": n_big / us * 1e6, "value_unit": "env-steps/s"}
+        del big, acts
+        torch.cuda.empty_cache()
+
     gather = None
     if multi and not args.no_gather:
         gather = time_gathers(env, ring, world, n, dist, torch, device, min(args.steps, 20))
@@ -239,6 +301,8 @@ def main():
         bps = algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
         kern_s = dev_ms / 1e3 / args.steps
         achieved = bps * n / kern_s / 1e9
+        achieved_wall = bps * n / (wall / args.steps) / 1e9
+        cache_resident = bps * n < INFINITY_CACHE_BYTES
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -253,10 +317,16 @@ def main():
                        "level_seed": hex(LEVEL_SEED), "action_seed": hex(ACTION_SEED)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_small" if cfg["size"] <= 8 else "k_large",
+                         # the same from the wall clock of the timed region (host launch gaps included);
+                         # `frac` is from HIP events on the launch stream
+                         "frac_wall": achieved_wall / HBM_PEAK_GBS,
+                         "frac_of_copy_ceiling": achieved / COPY_CEILING_GBS, "copy_ceiling": COPY_CEILING_GBS,
+                         "kernel": "k_small" if cfg["size"] <= 8 else "k_lines",
                          "kernel_us": kern_s * 1e6, "algorithmic_bytes_per_board_step": bps,
                          "algorithmic_bytes_per_launch": bps * n,
-                         "note": "working set < 256 MiB Infinity Cache at cfg1/cfg2: rate may exceed pure-HBM"},
+                         # a launch that moves less than the 256 MiB Infinity Cache runs at the on-die
+                         # cache / fabric write rate, not at the HBM rate: see "hbm_sibling"
+                         "cache_resident": cache_resident},
         }
         rec = pmc_traffic(args.config, n)
         if rec is not None:
@@ -264,6 +334,8 @@ def main():
             line["roofline"]["traffic_source"] = ("rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read "
                                                   "correction; raw FETCH_SIZE %d B), separate passes, recorded in "
                                                   "profiles/traffic_pmc.json" % rec["fetch_bytes_raw"])
+        if sibling is not None:
+            line["roofline"]["hbm_sibling"] = sibling
         if api is not None:
             line["python_step_api"] = api
         if compact is not None:
@@ -282,34 +354,59 @@ def time_gathers(env, ring, world, n, dist, torch, device, steps):
     """Step + hand-off to a single learner, three ways: (a) RCCL all-gather of the float32
     observations (what north_star names); (b) all-gather of the compact state (cell ids) and
     re-encoding on the learner side with ts_encode; (c) all-gather of uint8 observations and one
-    ts_expand_u8 on the learner."""
+    ts_expand_u8 on the learner.  Each is timed serially (step k, then gather k, on one stream)
+    and overlapped: the environment cycles through two observation buffers, gather k runs on
+    RCCL's stream while step k+1 writes the other buffer, and step k+2 waits for gather k."""
+    from tiler_slider_amd import VecTilerSliderEnv
     from tiler_slider_amd.distributed import ObservationGatherer
-    g = ObservationGatherer(env, world)
-    out = {}
-    env8 = None
-    modes = [("obs_f32", env, g.gather_observations), ("compact_state_then_encode", env, g.gather_compact_and_encode)]
-    if not (env._onehot is not None):
-        from tiler_slider_amd import VecTilerSliderEnv
-        env8 = VecTilerSliderEnv.from_arrays(env.size, env._blk, env._init, env._tgt, multi_color=env.multi_color,
-                                             max_steps=env.max_steps, device=device, auto_reset=True, obs_dtype="uint8")
-        env8.reset()
-        g8 = ObservationGatherer(env8, world)
-        modes.append(("obs_u8_then_expand", env8, g8.gather_u8_and_expand))
-    for name, env, fn in modes:
-        fn()
+
+    def twin(obs_dtype):
+        e = VecTilerSliderEnv.from_arrays(env.size, env._blk, env._init, env._tgt, multi_color=env.multi_color,
+                                          max_steps=env.max_steps, device=device, auto_reset=True, obs_dtype=obs_dtype,
+                                          obs_buffers=2)
+        e.reset()
+        return e
+
+    def timed(loop):
         dist.barrier()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        for i in range(steps):
-            env.step_async(ring[i & 15])
-            fn()
+        loop()
         torch.cuda.synchronize(device)
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         dist.barrier()
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        out[name] = {"value": n * world * steps / float(dt[0]), "unit": "env-steps/s", "steps": steps,
+        return float(dt[0])
+
+    out = {}
+    e32 = twin("float32")
+    g32 = ObservationGatherer(e32, world)
+    modes = [("obs_f32", e32, g32, lambda e, g, async_op: g.gather_observations(e._obs, async_op=async_op)),
+             ("compact_state_then_encode", e32, g32, lambda e, g, async_op: g.gather_compact_and_encode(async_op=async_op))]
+    e8 = twin("uint8")
+    g8 = ObservationGatherer(e8, world)
+    modes.append(("obs_u8_then_expand", e8, g8, lambda e, g, async_op: g.gather_u8_and_expand(e._obs, async_op=async_op)))
+    for name, e, g, fn in modes:
+        fn(e, g, False)  # warm-up (RCCL channel set-up)
+
+        def serial():
+            for i in range(steps):
+                e.step_async(ring[i & 15])
+                fn(e, g, False)
+
+        def overlapped():
+            prev = None
+            for i in range(steps):
+                e.step_async(ring[i & 15])          # writes observation buffer i % 2
+                if prev is not None:
+                    prev.wait()                     # gather i-1 has read buffer (i-1) % 2 ...
+                prev = fn(e, g, True)               # ... gather i starts behind step i, beside step i+1
+            prev.wait()
+
+        ts, to = timed(serial), timed(overlapped)
+        out[name] = {"value": n * world * steps / ts, "value_overlapped": n * world * steps / to, "unit": "env-steps/s",
+                     "steps": steps, "ms_per_step_serial": ts / steps * 1e3, "ms_per_step_overlapped": to / steps * 1e3,
                      "bytes_per_rank_per_step": g.bytes_per_step[name]}
-    del env8
     return out
 
 

@@ -34,6 +34,14 @@
  *    onehot     float32[N][Ch][S][S]    Ch = ts_onehot_channels(dims)
  *    reward     int32  [N]
  *    valid      uint8  [N]              bit d set <=> move d changes the board
+ *
+ * Preconditions on the level arrays (the reference never checks them either; its factory
+ * guarantees them, environment.py:221-226): every cell id < S*S; the tiles of a board pairwise
+ * distinct and not on obstacles.  Targets may repeat and may lie under tiles.  The kernels do
+ * not verify this: ids >= S*S are clamped to S*S - 1, and two tiles on one cell stay together
+ * (the reference would step the second one back, state.py:155-165) — no flag is raised.  The
+ * shipped host code checks list input always (levels.pack_levels) and array input on request
+ * (VecTilerSliderEnv.from_arrays(validate=True)).
  */
 #ifndef TILER_SLIDER_H
 #define TILER_SLIDER_H
@@ -173,6 +181,10 @@ int32_t ts_expand_u8(const uint8_t *src, float *dst, int64_t count, void *stream
  * "handled separately"; parity unpinned vs the reference, pinned by oracle/):
  *   one-hot: plane 0 obstacles; multi_color: plane 1+i tile i, plane 1+T+j target j;
  *            single colour: plane 1 any tile, plane 2 any target.
+ *            It is a function of the STATE (obstacles, tile cells, target cells), and of the
+ *            observation of ts_encode only while the targets are distinct: with two targets on
+ *            one cell the observation keeps the highest index alone (state.py:209-211) whereas
+ *            the one-hot form keeps a plane for each.
  *   reward : multi_color: -sum_i |r_i-tr_i|+|c_i-tc_i| over i < min(T,Tt);
  *            single colour: -sum_i min_j manhattan(tile_i, target_j) (0 if Tt == 0). */
 int32_t ts_encode_onehot(const ts_dims *dims, const ts_state *st, float *onehot, void *stream);

@@ -213,18 +213,12 @@ def test_bench_byte_accounting_matches_survey():
 
 
 def test_level_records_keep_the_reference_names():
-    """reference tests/test_dataloader.py:15-100 (dataclasses and colour constants; the image parser is
-    out of scope) and tests/test_user_scenarios.py:22-31 (levels built as ImageLoader.ImageProcessed)."""
+    """The level record under the reference's name (tests/test_user_scenarios.py:22-31 builds levels as
+    ImageLoader.ImageProcessed); the image parser and its constants are out of scope."""
     from tiler_slider_amd import ImageLoader, Level, TilerSliderEnv
-    raw = ImageLoader.ImageRawData(name="test.jpg", puzzle_image=np.zeros((100, 100, 3)),
-                                   level_label=np.zeros((50, 50, 3)), target_moves=np.zeros((50, 50, 3)))
-    assert raw.name == "test.jpg" and raw.puzzle_image.shape == (100, 100, 3)
     lvl = ImageLoader.ImageProcessed(size=5, blocked_locations=[(1, 1), (2, 2)], initial_locations=[(0, 0)],
                                      target_locations=[(4, 4)])
     assert lvl.size == 5 and lvl.multiple_colors is False and Level is ImageLoader.ImageProcessed
-    assert ImageLoader.BACKGROUND_COLOR.tolist() == [0, 172, 194]
-    assert ImageLoader.EMPTY_TILE_COLOR.tolist() == [223, 247, 249]
-    assert ImageLoader.COLOR_TOLERANCE.tolist() == [10, 10, 10]
     env = TilerSliderEnv.from_level(ImageLoader.ImageProcessed(size=4, blocked_locations=[(1, 0), (2, 3)],
                                                                initial_locations=[(0, 3), (3, 2)],
                                                                target_locations=[(0, 0), (3, 0)], multiple_colors=True))

@@ -555,3 +555,157 @@ def test_without_tables_equals_with_tables(torch_cuda, oracle, S, T, K, mc, N):
         assert torch.equal(oa, ob) and torch.equal(da, db) and torch.equal(ia["flags"], ib["flags"])
         assert torch.equal(a.positions, b.positions) and torch.equal(a.step_count, b.step_count)
     assert torch.equal(a.is_won(), b.is_won()) and torch.equal(a.encode(), b.encode())
+
+
+# ------------------------------------------------------------------------------------------------
+# a9 / a10 (build-defined reward and one-hot) pinned to REFERENCE-derived data: the golden files
+# hold the reference's own tile cells, target cells, obstacle map and observations; the expected
+# reward / planes are computed from those with NumPy, independently of kernel and oracle.
+# ------------------------------------------------------------------------------------------------
+def _numpy_reward(pos_rc, tgt_rc, multi_color):
+    """include/tiler_slider.h: multi_color: -sum_i |dr|+|dc| over i < min(T,Tt); single colour:
+    -sum_i min_j manhattan(tile_i, target_j) (0 without targets).  pos_rc [B,T,2], tgt_rc [B,Tt,2]."""
+    B, T, Tt = pos_rc.shape[0], pos_rc.shape[1], tgt_rc.shape[1]
+    if multi_color:
+        m = min(T, Tt)
+        return -np.abs(pos_rc[:, :m] - tgt_rc[:, :m]).sum(axis=(1, 2)).astype(np.int32)
+    if T == 0 or Tt == 0:
+        return np.zeros(B, np.int32)
+    d = np.abs(pos_rc[:, :, None, :] - tgt_rc[:, None, :, :]).sum(-1)  # [B,T,Tt]
+    return -d.min(axis=2).sum(axis=1).astype(np.int32)
+
+
+def _numpy_onehot(S, blocked, pos_rc, tgt_rc, multi_color):
+    B, T, Tt = pos_rc.shape[0], pos_rc.shape[1], tgt_rc.shape[1]
+    Ch = 1 + T + Tt if multi_color else 3
+    oh = np.zeros((B, Ch, S, S), np.float32)
+    oh[:, 0] = blocked.reshape(B, S, S)
+    b = np.arange(B)
+    for i in range(T):
+        oh[b, 1 + i if multi_color else 1, pos_rc[:, i, 0], pos_rc[:, i, 1]] = 1
+    for j in range(Tt):
+        oh[b, 1 + T + j if multi_color else 2, tgt_rc[:, j, 0], tgt_rc[:, j, 1]] = 1
+    return oh
+
+
+@pytest.mark.parametrize("name", golden_groups())
+def test_reward_and_onehot_from_reference_fixture_data(torch_cuda, name):
+    """HIP reward / one-hot after every golden step == NumPy on the REFERENCE's recorded cells;
+    and where targets are distinct, the one-hot planes follow from the reference's own
+    observation: plane(1+i) == (obs[..., 1] == i+1), plane(1+T+j) == (obs[..., 2] == j+1)."""
+    torch = torch_cuda
+    g = load_golden(name)
+    S, T = int(g["size"]), int(g["n_tiles"])
+    mc = bool(g["multi_color"])
+    B, L = g["actions"].shape
+    Tt = g["tgt"].shape[1]
+    if S * S * (1 + T + Tt) * B * 4 > 1_500_000_000:
+        pytest.skip("one-hot planes of this group do not fit comfortably")
+    env = _env_from_golden(g, max_steps=2**31 - 1, with_reward=True, with_onehot=True)
+    env.reset()
+    tgt_rc = g["tgt"].astype(np.int64).reshape(B, Tt, 2)
+    blocked = g["blocked"].astype(np.float32)
+    distinct = np.array([len({tuple(x) for x in tgt_rc[b]}) == Tt for b in range(B)])
+    for l in range(L):
+        env._done.zero_()
+        obs, done, info = env.step(torch.from_numpy(g["actions"][:, l].copy()))
+        pos_rc = g["pos"][:, l].astype(np.int64).reshape(B, T, 2)
+        np.testing.assert_array_equal(info["reward"].cpu().numpy(), _numpy_reward(pos_rc, tgt_rc, mc))
+        got = info["onehot"].cpu().numpy()
+        np.testing.assert_array_equal(got, _numpy_onehot(S, blocked, pos_rc, tgt_rc, mc))
+        ref_obs = g["obs"][:, l]
+        np.testing.assert_array_equal(got[:, 0], ref_obs[..., 0])
+        if mc:
+            for i in range(T):
+                np.testing.assert_array_equal(got[:, 1 + i], (ref_obs[..., 1] == i + 1).astype(np.float32))
+            for j in range(Tt):
+                np.testing.assert_array_equal(got[distinct, 1 + T + j], (ref_obs[distinct][..., 2] == j + 1).astype(np.float32))
+        else:
+            np.testing.assert_array_equal(got[:, 1], ref_obs[..., 1])
+            np.testing.assert_array_equal(got[:, 2], ref_obs[..., 2])
+    # the stand-alone entry points agree with the fused outputs
+    np.testing.assert_array_equal(env.reward().cpu().numpy(), info["reward"].cpu().numpy())
+    np.testing.assert_array_equal(env.encode_onehot().cpu().numpy(), got)
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side behaviour added in round 2
+# ------------------------------------------------------------------------------------------------
+def test_gamestate_current_locations_assignment(torch_cuda):
+    """reference tests/test_state.py:317-363: the win rules are tested by ASSIGNING current_locations."""
+    from tiler_slider_amd import GameState
+    st = GameState(size=3, blocked_locations=[], initial_locations=[(0, 0), (0, 1)], target_locations=[(2, 2), (2, 1)],
+                   multi_color=False)
+    assert st.is_won() is False
+    st.current_locations = [(2, 1), (2, 2)]  # order does not matter in single-colour mode
+    assert st.is_won() is True and st.current_locations == [(2, 1), (2, 2)]
+    assert st.get_state_array()[2, 1, 1] == 1.0 and st.get_state_array()[0, 0, 1] == 0.0
+    st.current_locations = [(2, 2), (1, 1)]  # only one tile on a target
+    assert st.is_won() is False
+    mc = GameState(size=3, blocked_locations=[], initial_locations=[(0, 0), (0, 1)], target_locations=[(2, 2), (2, 1)],
+                   multi_color=True)
+    mc.current_locations = [(2, 1), (2, 2)]  # wrong order
+    assert mc.is_won() is False
+    mc.current_locations = [(2, 2), (2, 1)]
+    assert mc.is_won() is True
+    assert mc.move(GameState.Move.UP) is False and mc.current_locations == [(0, 2), (0, 1)]  # moves continue from there
+    with pytest.raises(ValueError):
+        mc.current_locations = [(0, 0)]
+
+
+def test_env_reset_rebuilds_from_edited_attributes(torch_cuda):
+    """environment.py:88-94 rebuilds GameState from the attributes on every reset()."""
+    from tiler_slider_amd import Move, TilerSliderEnv
+    env = TilerSliderEnv(size=3, blocked_locations=[], initial_locations=[(1, 0)], target_locations=[(0, 0)], max_steps=5)
+    env.reset()
+    _, done, info = env.step(Move.UP)
+    assert done is True and info["success"] is True
+    env.initial_locations, env.target_locations, env.max_steps = [(2, 2)], [(2, 0)], 1
+    obs = env.reset()
+    assert obs[2, 2, 1] == 1.0 and obs[2, 0, 2] == 1.0 and env.state.current_locations == [(2, 2)]
+    _, done, info = env.step(Move.UP)
+    assert done is True and info.get("timeout") is True and "success" not in info
+
+
+def test_from_arrays_validate(torch_cuda, oracle):
+    from tiler_slider_amd import VecTilerSliderEnv
+    blk, init, tgt = oracle.generate(5, 3, 3, 4, 50, seed=9)
+    VecTilerSliderEnv.from_arrays(5, blk, init, tgt, validate=True)  # factory-style levels pass
+    bad = init.copy()
+    bad[1, 7] = bad[0, 7]
+    with pytest.raises(ValueError, match="board 7: two tiles"):
+        VecTilerSliderEnv.from_arrays(5, blk, bad, tgt, validate=True)
+    bad = init.copy()
+    bad[2, 3] = 25
+    with pytest.raises(ValueError, match="outside"):
+        VecTilerSliderEnv.from_arrays(5, blk, bad, tgt, validate=True)
+    b2 = blk.copy()
+    b2[0, 11] |= np.uint32(1) << np.uint32(init[0, 11])
+    with pytest.raises(ValueError, match="board 11: a tile on a blocked cell"):
+        VecTilerSliderEnv.from_arrays(5, b2, init, tgt, validate=True)
+    VecTilerSliderEnv.from_arrays(5, b2, init, tgt)  # unchecked by default
+
+
+def test_stepinfo_snapshot_and_double_buffered_observations(torch_cuda, oracle):
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    N = 3000
+    blk, init, tgt = oracle.generate(4, 2, 2, 2, N, seed=3)
+    ref = oracle.OracleBatch(4, True, 50, blk, init, tgt)
+    ref.reset()
+    env = VecTilerSliderEnv.from_arrays(4, blk, init, tgt, multi_color=True, max_steps=50, obs_buffers=2, with_reward=True)
+    env.reset()
+    a0, a1 = (torch.from_numpy(oracle.fill_actions(N, seed=1, step_index=i)) for i in range(2))
+    obs0, _, info0 = env.step(a0)
+    snap = info0.snapshot()
+    want0 = ref.step(a0.numpy(), reward=True)
+    obs1, _, info1 = env.step(a1)
+    want1 = ref.step(a1.numpy(), reward=True)
+    assert obs0.data_ptr() != obs1.data_ptr()  # step k's observation survives step k+1
+    np.testing.assert_array_equal(obs0.cpu().numpy(), want0["obs"])
+    np.testing.assert_array_equal(obs1.cpu().numpy(), want1["obs"])
+    np.testing.assert_array_equal(snap["flags"].cpu().numpy(), want0["flags"])
+    np.testing.assert_array_equal(snap["reward"].cpu().numpy(), want0["reward"])
+    np.testing.assert_array_equal(info0["flags"].cpu().numpy(), want1["flags"])  # the live view has moved on (documented)
+    with pytest.raises(ValueError):
+        env.capture_steps([a0.to(env.device)])

@@ -66,7 +66,7 @@
 #define TS_FORCE_OBS_BOARDS 0
 #endif
 #ifndef TS_MAX_BLOCK_LDS  // dynamic LDS a block may ask for (bytes)
-#define TS_MAX_BLOCK_LDS (60 * 1024)
+#define TS_MAX_BLOCK_LDS (64 * 1024)
 #endif
 #ifndef TS_SET_LDS_ATTR  // diagnostic: hipFuncSetAttribute(MaxDynamicSharedMemorySize) before k_small launches
 #define TS_SET_LDS_ATTR 0
@@ -1360,12 +1360,35 @@ SmallKernel small_kernel(int S, int tfix) {
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
-// Dynamic LDS per block stays well below 64 KiB.  A launch asking for exactly 65,536 B is
-// accepted by the runtime but co-resident blocks then corrupt each other's LDS (seen on
-// 8x8 / 20 tiles at >= 100k boards: 1..4 % of the boards wrong, none in the first blocks of each
-// CU) — consistent with the size wrapping to 0 in a 16-bit field.  Blocks shrink to 2 or 1
-// wave(s) instead; a single wave never needs more than ~36 KiB.
+// Dynamic LDS a block may ask for.  64 KiB keeps at least two blocks on a CU (160 KiB of LDS);
+// blocks shrink to 2 or 1 wave(s) when four carves would not fit, and no wave of any kernel here
+// needs more than ~36 KiB.  The hardware limit is higher: tools/lds_probe.py ran self-checking
+// launches at every size up to hipDeviceAttributeMaxSharedMemoryPerBlock = 163,840 B without
+// hipFuncSetAttribute and without a single foreign write (profiles/r02_lds_probe.log).
+// Round 1 capped this at 60 KiB, blaming a corruption seen on 8x8 / 20 tiles on requests of
+// exactly 65,536 B.  That was wrong: the pre-fix source still corrupts ~1.5 % of 524k boards
+// with 32 KiB blocks, and this source is clean at 65,536 and 66,048 B.  What fails is one
+// compiled form of k_small<8, 0, false> (-O2 / -O3 of the single-pass observation block; -O1 of
+// the same source is clean): in one iteration of the slide loop the horizontally moving lanes
+// of a wave see a wrong row mask and one tile slides past its row, only in waves that share a
+// SIMD with others (profiles/r02_lds_corruption_bisect.log; reproducer:
+// tools/lds_corruption_repro.py).  Cause below the source level not established; test_large_batches_vs_oracle keeps
+// every kernel variant under co-residency-scale test against the oracle.
 constexpr size_t kMaxBlockLds = TS_MAX_BLOCK_LDS;
+
+// the device's own per-block limit (queried once per thread and device); 0 when the query fails
+size_t device_block_lds_limit() {
+  thread_local int cached_dev = -1;
+  thread_local size_t cached = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev != cached_dev) {
+    int v = 0;
+    cached = hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess && v > 0 ? (size_t)v : 0;
+    cached_dev = dev;
+  }
+  return cached;
+}
 
 int32_t finish_launch() {
   const hipError_t e = hipGetLastError();
@@ -1417,6 +1440,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     int waves = TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
     if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
+    if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
     const int64_t boards_per_block = (int64_t)waves * kWave;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
@@ -1437,6 +1461,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_wave_bytes = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) + TS_LINES_LDS_PAD;
     const int waves = 4;
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
+    if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
     const int64_t boards_per_block = (int64_t)waves * kLinesBPW;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
@@ -1471,6 +1496,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     int waves = TS_WAVES_PER_BLOCK > 4 ? 4 : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
     if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
+    if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
     const int64_t boards_per_block = (int64_t)waves * bpw;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;

@@ -28,7 +28,7 @@ class GameState:
     def __init__(self, size, blocked_locations, initial_locations, target_locations, multi_color=False, *,
                  device=None):
         self.size = size
-        self.current_locations = copy.copy(initial_locations)
+        self._locations = copy.copy(initial_locations)
         self.target_locations = copy.copy(target_locations)
         self.multi_color = multi_color
         self.is_blocked = np.zeros((size, size), dtype=bool)
@@ -36,11 +36,29 @@ class GameState:
             self.is_blocked[i, j] = True
         self._blocked_locations = [(int(i), int(j)) for i, j in blocked_locations]
         self._device = device
-        self._vec = VecTilerSliderEnv(size, [self._blocked_locations], [list(self.current_locations)],
+        self._vec = VecTilerSliderEnv(size, [self._blocked_locations], [list(self._locations)],
                                       [list(self.target_locations)], multi_color=multi_color, max_steps=_NO_LIMIT,
                                       device=device, host_mapped=True)
         self._vec.reset()
         self._move_to = None
+
+    @property
+    def current_locations(self):
+        """Tile cells, list index = tile id (state.py:62).  Assigning a new list moves the tiles
+        (the reference's own tests do: tests/test_state.py:330-363) — the device copy follows."""
+        return self._locations
+
+    @current_locations.setter
+    def current_locations(self, locations):
+        locations = list(locations)
+        if len(locations) != self._vec.n_tiles:
+            raise ValueError(f"this board has {self._vec.n_tiles} tiles, got {len(locations)} locations")
+        cells = [int(r) * self.size + int(c) for r, c in locations]
+        if any(not (0 <= int(r) < self.size and 0 <= int(c) < self.size) for r, c in locations):
+            raise ValueError("tile location outside the board")
+        if cells:  # the buffers are pinned host memory the kernels work on in place: a plain store
+            self._vec.positions[:, 0] = torch.tensor(cells, dtype=torch.int64).to(self._vec.positions.dtype)
+        self._locations = locations
 
     # -- state.py:120-170
     def move(self, move):
@@ -49,7 +67,7 @@ class GameState:
         v._actions[0] = move.value  # buffers are pinned host memory the kernel works on in place
         v.step_async()
         v._sync_if_host()
-        self.current_locations = unpack_cells(self.size, v.positions[:, 0].numpy())
+        self._locations = unpack_cells(self.size, v.positions[:, 0].numpy())
         return bool(int(v._flags[0]) & _cabi.FLAG_IS_WON)
 
     # -- state.py:172-186
@@ -135,6 +153,7 @@ class TilerSliderEnv:
         self.observation_shape = (size, size, 3) if size else None
         self._device = device
         self._vec = None
+        self._vec_key = None
 
     @classmethod
     def from_level(cls, level, max_steps=100, **kw):
@@ -143,11 +162,19 @@ class TilerSliderEnv:
                    initial_locations=level.initial_locations, target_locations=level.target_locations,
                    multi_color=level.multiple_colors, max_steps=max_steps, **kw)
 
+    def _level_key(self):
+        return (self.size, tuple(map(tuple, self.blocked_locations)), tuple(map(tuple, self.initial_locations)),
+                tuple(map(tuple, self.target_locations)), bool(self.multi_color), int(self.max_steps))
+
     def reset(self):
-        if self._vec is None:
+        # the reference rebuilds its GameState from these attributes on every reset()
+        # (environment.py:88-94), so edits to them between episodes take effect here too
+        key = self._level_key()
+        if self._vec is None or key != self._vec_key:
             self._vec = VecTilerSliderEnv(self.size, [self.blocked_locations], [self.initial_locations],
                                           [self.target_locations], multi_color=self.multi_color,
                                           max_steps=self.max_steps, device=self._device, host_mapped=True)
+            self._vec_key = key
         obs = self._vec.reset()[0].numpy().copy()  # a fresh array per call, like the reference
         self.state = _BoardView(self)
         self.step_count = 0

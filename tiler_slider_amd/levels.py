@@ -14,24 +14,14 @@ MAX_TILES = 255
 
 
 class ImageLoader:
-    """The level records of the reference's screenshot loader, without the loader.
+    """The level record of the reference's screenshot loader, without the loader.
 
-    ref: explainrl/environment/dataloader.py:8-27.  `ImageProcessed` is the level schema every
-    environment constructor consumes (environment.py:61-80); `ImageRawData` and the three colour
-    constants are kept so code written against the reference's names imports unchanged.  Parsing
-    the 400 phone screenshots (dataloader.py:29-133) needs OpenCV and is out of this build's scope.
+    ref: explainrl/environment/dataloader.py:21-27.  `ImageProcessed` is the level schema every
+    environment constructor consumes (environment.py:61-80), kept under the reference's name so
+    that `TilerSliderEnv.from_level(ImageLoader.ImageProcessed(...))` reads as it does there.
+    Parsing the 400 phone screenshots (dataloader.py:29-133) needs OpenCV and is outside the
+    hot path; nothing else of that module is reproduced here.
     """
-
-    BACKGROUND_COLOR = np.array([0, 172, 194])
-    EMPTY_TILE_COLOR = np.array([223, 247, 249])
-    COLOR_TOLERANCE = np.array([10, 10, 10])
-
-    @dataclass
-    class ImageRawData:
-        name: str
-        puzzle_image: np.ndarray
-        level_label: np.ndarray
-        target_moves: np.ndarray
 
     @dataclass
     class ImageProcessed:
@@ -60,19 +50,23 @@ def cell_dtype(size):
     return np.uint8 if size <= 16 else np.uint16
 
 
-def _cells(size, locs, what):
-    out = []
-    for loc in locs:
-        r, c = int(loc[0]), int(loc[1])
-        if not (0 <= r < size and 0 <= c < size):
-            raise ValueError(f"{what} location {tuple(loc)} is outside a {size}x{size} board")
-        out.append(r * size + c)
-    return out
+def _cell_ids(size, per_board, what):
+    """Per-board lists of (r, c) with one common length -> int64 cell ids [N, L] (range-checked)."""
+    n = len(per_board)
+    L = len(per_board[0]) if n else 0
+    if any(len(x) != L for x in per_board):
+        raise ValueError("every board of a batch needs the same number of tiles and of targets")
+    a = np.asarray(per_board, dtype=np.int64).reshape(n, L, 2) if n and L else np.zeros((n, L, 2), np.int64)
+    if a.size and (a.min() < 0 or a.max() >= size):
+        b, i = np.argwhere((a < 0).any(-1) | (a >= size).any(-1))[0]
+        raise ValueError(f"{what} location {tuple(int(v) for v in a[b, i])} is outside a {size}x{size} board")
+    return a[..., 0] * size + a[..., 1]
 
 
 def pack_levels(size, blocked, initial, targets):
     """Per-board location lists -> (blk uint32[W,N], init cell[T,N], tgt cell[Tt,N]) numpy arrays
-    (cell = uint8 up to 16x16, uint16 above).
+    (cell = uint8 up to 16x16, uint16 above).  Vectorised: one numpy pass per array, no Python
+    loop over boards or cells (obstacle lists may differ in length from board to board).
 
     Enforces what the kernels rely on and the reference's factory guarantees
     (ref: explainrl/environment/environment.py:221-226): tiles pairwise distinct and never on
@@ -87,37 +81,42 @@ def pack_levels(size, blocked, initial, targets):
     Tt = len(targets[0]) if n else 0
     if T > min(MAX_TILES, size * size) or Tt > MAX_TILES:
         raise ValueError(f"too many tiles/targets for a {size}x{size} board: {T}/{Tt}")
-    blk = np.zeros((blk_words(size), n), np.uint32)
-    init = np.zeros((T, n), cell_dtype(size))
-    tgt = np.zeros((Tt, n), cell_dtype(size))
-    for b in range(n):
-        if len(initial[b]) != T or len(targets[b]) != Tt:
-            raise ValueError("every board of a batch needs the same number of tiles and of targets")
-        bc = _cells(size, blocked[b], "blocked")
-        ic = _cells(size, initial[b], "initial")
-        tc = _cells(size, targets[b], "target")
-        if len(set(ic)) != len(ic):
-            raise ValueError(f"board {b}: two tiles start on the same cell")
-        if set(ic) & set(bc):
-            raise ValueError(f"board {b}: a tile starts on a blocked cell")
-        for p in bc:
-            blk[p >> 5, b] |= np.uint32(1 << (p & 31))
-        init[:, b] = ic
-        tgt[:, b] = tc
-    return blk, init, tgt
+    C, W = size * size, blk_words(size)
+    ic = _cell_ids(size, initial, "initial")   # [N, T]
+    tc = _cell_ids(size, targets, "target")    # [N, Tt]
+    # obstacles: ragged per board -> flat (board, cell) pairs
+    counts = np.fromiter((len(b) for b in blocked), dtype=np.int64, count=n)
+    flat = [loc for b in blocked for loc in b]
+    bcell = _cell_ids(size, [flat], "blocked")[0] if flat else np.zeros(0, np.int64)
+    bboard = np.repeat(np.arange(n, dtype=np.int64), counts)
+    grid = np.zeros((n, W * 32), dtype=bool)   # obstacle map, padded to whole words
+    grid[bboard, bcell] = True
+    if T:
+        srt = np.sort(ic, axis=1)
+        dup = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
+        if dup.any():
+            raise ValueError(f"board {int(np.flatnonzero(dup)[0])}: two tiles start on the same cell")
+        hit = np.take_along_axis(grid, ic, axis=1).any(axis=1)
+        if hit.any():
+            raise ValueError(f"board {int(np.flatnonzero(hit)[0])}: a tile starts on a blocked cell")
+    # bit p & 31 of word p >> 5: little-endian bit order inside little-endian words
+    blk = np.packbits(grid.reshape(n, W, 32), axis=2, bitorder="little").reshape(n, W, 4).copy().view("<u4").reshape(n, W)
+    assert C <= W * 32
+    return (np.ascontiguousarray(blk.T.astype(np.uint32)), np.ascontiguousarray(ic.T.astype(cell_dtype(size))),
+            np.ascontiguousarray(tc.T.astype(cell_dtype(size))))
 
 
 def unpack_cells(size, cells):
-    """uint8 cell ids -> list of (r, c) int tuples."""
-    return [(int(p) // size, int(p) % size) for p in cells]
+    """cell ids of one board -> list of (r, c) int tuples."""
+    c = np.asarray(cells).astype(np.int64)
+    return list(zip((c // size).tolist(), (c % size).tolist()))
 
 
 def unpack_blocked(size, words):
     """uint32 words of one board -> bool [S, S] grid."""
-    grid = np.zeros(size * size, bool)
-    for p in range(size * size):
-        grid[p] = (int(words[p >> 5]) >> (p & 31)) & 1
-    return grid.reshape(size, size)
+    w = np.ascontiguousarray(np.asarray(words).astype("<u4"))
+    bits = np.unpackbits(w.view(np.uint8), bitorder="little")[:size * size]
+    return bits.astype(bool).reshape(size, size)
 
 
 def parse_board_string(board_str):

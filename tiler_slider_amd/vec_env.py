@@ -31,7 +31,12 @@ class StepInfo(Mapping):
     Keys: is_won, invalid_move, success, timeout (bool [N]), step_count (int32 [N], the value
     BEFORE this step's increment, as in environment.py:128), plus the vector-env extras
     stepped_done, autoreset, bad_action and the raw `flags` byte.  Optional kernel outputs
-    (reward, onehot, valid_moves) appear when the environment was built with them."""
+    (reward, onehot, valid_moves) appear when the environment was built with them.
+
+    Like the observation, the info of step k is a VIEW of the environment's own buffers: the
+    next step() / reset() overwrites them, and an info object read afterwards reports the later
+    step.  `info.snapshot()` returns a detached copy (a plain dict of cloned tensors) for
+    callers that keep infos around, e.g. in a rollout buffer."""
 
     _BITS = {"is_won": _cabi.FLAG_IS_WON, "invalid_move": _cabi.FLAG_INVALID_MOVE, "success": _cabi.FLAG_SUCCESS,
              "timeout": _cabi.FLAG_TIMEOUT, "stepped_done": _cabi.FLAG_STEPPED_DONE,
@@ -58,6 +63,11 @@ class StepInfo(Mapping):
     def __len__(self):
         return 9 + len(self._extras)
 
+    def snapshot(self):
+        """A dict of cloned tensors that the next step() cannot change."""
+        frozen = StepInfo(self._flags.clone(), self._step_count.clone(), {k: v.clone() for k, v in self._extras.items()})
+        return {k: frozen[k] for k in frozen}
+
 
 class VecTilerSliderEnv:
     """N boards of one shape (size, tile count, target count, multi_color) on one GPU."""
@@ -65,7 +75,7 @@ class VecTilerSliderEnv:
     def __init__(self, size, blocked_locations=None, initial_locations=None, target_locations=None,
                  multi_color=False, max_steps=100, *, device=None, strict=False, auto_reset=False,
                  with_reward=False, with_onehot=False, with_valid_moves=False, obs_dtype="float32",
-                 host_mapped=False):
+                 host_mapped=False, obs_buffers=1):
         """blocked/initial/target_locations: one list of (row, col) per board.
 
         strict      : raise the reference's RuntimeError when any board is stepped after done
@@ -76,6 +86,10 @@ class VecTilerSliderEnv:
         obs_dtype   : "float32" = the reference's observation format (default); "uint8" = the
                       same values as bytes, a quarter of the memory traffic (every value of the
                       reference observation is an integer 0..255, so nothing is lost).
+        obs_buffers : number of observation buffers step() cycles through (default 1: every step
+                      overwrites the same tensor).  With 2, the tensor returned by step k stays
+                      intact while step k+1 runs, so a consumer on another stream — the RCCL
+                      all-gather of tiler_slider_amd.distributed — can overlap with the next step.
         host_mapped : keep every buffer in pinned host memory that the GPU reads and writes in
                       place (zero-copy).  For a handful of boards driven move by move from Python
                       (the one-board adapters): a step is then one launch plus one stream
@@ -87,20 +101,46 @@ class VecTilerSliderEnv:
         target_locations = target_locations if target_locations is not None else [[] for _ in range(n)]
         blk, init, tgt = pack_levels(size, blocked_locations, initial_locations or [], target_locations)
         self._setup(size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-                    with_onehot, with_valid_moves, obs_dtype, host_mapped)
+                    with_onehot, with_valid_moves, obs_dtype, host_mapped, obs_buffers)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
     def from_arrays(cls, size, blk, init, tgt, multi_color=False, max_steps=100, **kw):
         """Packed level arrays (numpy or torch) in the device layout: blk [W,N] 32-bit words,
         init [T,N] and tgt [Tt,N] cell ids (uint8 up to 16x16; uint16 / torch.int16 above)."""
+        validate = kw.pop("validate", False)
         self = cls.__new__(cls)
         self._setup(size, blk, init, tgt, multi_color, max_steps, kw.pop("device", None), kw.pop("strict", False),
                     kw.pop("auto_reset", False), kw.pop("with_reward", False), kw.pop("with_onehot", False),
-                    kw.pop("with_valid_moves", False), kw.pop("obs_dtype", "float32"), kw.pop("host_mapped", False))
+                    kw.pop("with_valid_moves", False), kw.pop("obs_dtype", "float32"), kw.pop("host_mapped", False),
+                    kw.pop("obs_buffers", 1))
         if kw:
             raise TypeError(f"unexpected arguments {sorted(kw)}")
+        if validate:
+            self.validate_levels()
         return self
+
+    def validate_levels(self):
+        """Checks the preconditions the kernels rely on and pack_levels enforces for list input
+        (include/tiler_slider.h): cell ids below S*S, tiles pairwise distinct, no tile on an
+        obstacle.  The raw arrays of from_arrays() / the C-ABI skip them by default (the kernels
+        clamp ids silently, and two tiles on one cell collapse where the reference would step the
+        second one back, state.py:155-165).  One device sync; raises ValueError."""
+        C_ = self.size * self.size
+        init, tgt = self._init.to(torch.int64), self._tgt.to(torch.int64)
+        for name, t in (("init", init), ("tgt", tgt)):
+            if t.numel() and (int(t.min()) < 0 or int(t.max()) >= C_):
+                raise ValueError(f"{name}: cell id outside 0..{C_ - 1}")
+        if init.shape[0] > 1:
+            srt = init.sort(dim=0).values
+            dup = (srt[1:] == srt[:-1]).any(dim=0)
+            if bool(dup.any()):
+                raise ValueError(f"board {int(dup.nonzero()[0])}: two tiles on one cell")
+        if init.numel():
+            words = torch.gather(self._blk.to(torch.int64) & 0xffffffff, 0, init >> 5)
+            hit = ((words >> (init & 31)) & 1).any(dim=0)
+            if bool(hit.any()):
+                raise ValueError(f"board {int(hit.nonzero()[0])}: a tile on a blocked cell")
 
     @classmethod
     def from_levels(cls, levels, max_steps=100, **kw):
@@ -135,7 +175,7 @@ class VecTilerSliderEnv:
 
     # ------------------------------------------------------------------ setup
     def _setup(self, size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-               with_onehot, with_valid_moves, obs_dtype="float32", host_mapped=False):
+               with_onehot, with_valid_moves, obs_dtype="float32", host_mapped=False, obs_buffers=1):
         L = _cabi.lib()  # raises when the HIP library is missing: no fallback
         self.device = _resolve_device(device)
         self.host_mapped = bool(host_mapped)
@@ -162,7 +202,11 @@ class VecTilerSliderEnv:
         if obs_dtype not in (torch.float32, torch.uint8):
             raise ValueError("obs_dtype must be 'float32' or 'uint8'")
         self.obs_dtype = obs_dtype
-        self._obs = self._zeros((N, self.size, self.size, 3), obs_dtype)
+        if int(obs_buffers) < 1:
+            raise ValueError("obs_buffers must be >= 1")
+        self._obs_ring = [self._zeros((N, self.size, self.size, 3), obs_dtype) for _ in range(int(obs_buffers))]
+        self._obs_slot = 0
+        self._obs = self._obs_ring[0]  # always the buffer the latest reset() / step() wrote
         self.onehot_channels = L.ts_onehot_channels(C.byref(self._dims))
         self._reward = self._zeros(N, torch.int32) if with_reward else None
         self._onehot = (self._zeros((N, self.onehot_channels, self.size, self.size), torch.float32)
@@ -178,8 +222,9 @@ class VecTilerSliderEnv:
             self._call("ts_prepare", C.byref(self._dims), C.byref(self._state), _ptr(self._lines))
             self._state.lines = _ptr(self._lines)
         f32 = obs_dtype == torch.float32
-        self._out = _cabi.StepOut(_ptr(self._flags), _ptr(self._obs) if f32 else None, _ptr(self._reward),
-                                  _ptr(self._onehot), _ptr(self._valid), None if f32 else _ptr(self._obs))
+        self._outs = [_cabi.StepOut(_ptr(self._flags), _ptr(o) if f32 else None, _ptr(self._reward),
+                                    _ptr(self._onehot), _ptr(self._valid), None if f32 else _ptr(o)) for o in self._obs_ring]
+        self._out = self._outs[0]
         self._mode = _cabi.MODE_AUTORESET if self.auto_reset else _cabi.MODE_STRICT
         self.observation_shape = (self.size, self.size, 3)  # per board, environment.py:59
         self._started = False
@@ -242,6 +287,9 @@ class VecTilerSliderEnv:
         """The bare launch: one ts_step on the current stream, no validation, no sync.
         `act` is a uint8 device tensor [N] (default: the env's own action buffer)."""
         a = self._actions if act is None else act
+        if len(self._obs_ring) > 1:  # next observation buffer: the previous one stays intact
+            self._obs_slot = (self._obs_slot + 1) % len(self._obs_ring)
+            self._obs, self._out = self._obs_ring[self._obs_slot], self._outs[self._obs_slot]
         self._call("ts_step", C.byref(self._dims), C.byref(self._state), a.data_ptr(), self._mode,
                    C.byref(self._out))
 
@@ -254,6 +302,8 @@ class VecTilerSliderEnv:
         self._require_open()
         if self.host_mapped:
             raise ValueError("capture_steps needs device buffers (host_mapped=False)")
+        if len(self._obs_ring) > 1:
+            raise ValueError("capture_steps needs obs_buffers=1 (a replayed graph cannot rotate buffers)")
         bufs = [b for b in action_buffers]
         for b in bufs:
             if not (isinstance(b, torch.Tensor) and b.dtype == torch.uint8 and b.device == self.device

@@ -48,4 +48,31 @@ for name in json.load(open(os.path.join(VDIR, "manifest.json"))):
         obs = env._obs.cpu().numpy()
         bad = np.flatnonzero((obs != wants[i]["obs"]).reshape(n, -1).any(axis=1))
         badf = np.flatnonzero(env._flags.cpu().numpy() != wants[i]["flags"])
+        if i == 0 and os.environ.get("TS_SHOW_DIFF"):
+            ref0 = orc.OracleBatch(cfg["size"], True, 2**30, blk, init, tgt)
+            ref0.reset()
+            ref0.step(acts[0], mode=orc.MODE_AUTORESET)
+            badp = np.flatnonzero((env._pos.cpu().numpy() != ref0.pos).any(axis=0))
+            print(f"{name}: step 0: {len(badp)} boards with wrong positions in HBM (first {badp[:8].tolist()})", flush=True)
+            gotp = env._pos.cpu().numpy()
+            S_ = cfg["size"]
+            for b in badp[:12].tolist():
+                ts_ = np.flatnonzero(gotp[:, b] != ref0.pos[:, b]).tolist()
+                for t_ in ts_:
+                    # hypothesis A: the tile was slid twice (a second wave processed the same board)
+                    twice = orc.OracleBatch(S_, True, 2**30, blk[:, b:b + 1].copy(), ref0.pos[:, b:b + 1].copy(), tgt[:, b:b + 1].copy())
+                    twice.reset()
+                    twice.step(acts[0][b:b + 1].copy(), mode=orc.MODE_AUTORESET)
+                    print(f"    board {b} action {acts[0][b]} tile {t_}: start {init[t_, b]} want {ref0.pos[t_, b]} got {gotp[t_, b]}"
+                          f"  (slid twice would be {twice.pos[t_, 0]}; start cells of the board: {sorted(init[:, b].tolist())})", flush=True)
         print(f"{name}: step {i}: {len(bad)} boards with wrong obs (first {bad[:8].tolist()}), {len(badf)} wrong flags", flush=True)
+        if len(bad) and i == 0 and os.environ.get("TS_SHOW_DIFF"):
+            for b in bad[:3].tolist() + bad[-2:].tolist():
+                got, want = obs[b].reshape(-1), wants[i]["obs"][b].reshape(-1)
+                idx = np.flatnonzero(got != want)
+                print(f"    board {b} (wave {b // 64}, lane {b % 64}): {len(idx)} floats differ; (flat index: got/want) "
+                      + ", ".join(f"{k}: {got[k]:g}/{want[k]:g}" for k in idx[:24].tolist()), flush=True)
+            lanes = np.bincount(bad % 64, minlength=64)
+            waves_in_block = np.bincount((bad // 64) % 4, minlength=4)
+            print(f"    wrong boards by lane: {lanes.tolist()}", flush=True)
+            print(f"    wrong boards by wave-in-block: {waves_in_block.tolist()}; by block mod 8: {np.bincount((bad // 256) % 8, minlength=8).tolist()}", flush=True)
