@@ -219,6 +219,16 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
 int32_t ts_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int64_t board_offset,
                     int32_t n_obstacles, void *stream);
 
+/* The reference's own random levels, one board per 32-bit seed, bit for bit: board n is what
+ * TilerSliderEnvFactory.create_simple_env(size, num_tiles, num_obstacles, seed = seeds[n]) builds —
+ * numpy's legacy stream (MT19937 init_genrand(seed), list shuffle by masked rejection) restated on
+ * the device.  seeds: device uint32 [N].  Writes blk, init and tgt (cast away const); the first
+ * n_obstacles shuffled cells become obstacles, the next n_tiles tiles, the next n_targets targets.
+ * ref: explainrl/environment/environment.py:202-234 ("scramble"); numpy 2.3.4 (uv.lock:293-294)
+ *      numpy/random/mtrand.pyx RandomState.seed / shuffle, legacy-distributions random_interval. */
+int32_t ts_generate_mt19937(const ts_dims *dims, const ts_state *st, const uint32_t *seeds, int32_t n_obstacles,
+                            void *stream);
+
 /* actions[n] = uniform {0,1,2,3} from the counter-based stream (seed, step_index,
  * board_offset + n). */
 int32_t ts_fill_actions(int64_t n_boards, uint64_t seed, int64_t board_offset, int64_t step_index,

@@ -24,7 +24,7 @@ class Dims(C.Structure):
 
 class State(C.Structure):
     _fields_ = [("pos", C.c_void_p), ("init", C.c_void_p), ("tgt", C.c_void_p), ("blk", C.c_void_p),
-                ("step_count", C.c_void_p), ("done", C.c_void_p)]
+                ("step_count", C.c_void_p), ("done", C.c_void_p), ("lines", C.c_void_p)]
 
 
 class StepOut(C.Structure):
@@ -69,6 +69,7 @@ def lib():
         L.tso_encode_onehot.argtypes = [DP, SP, P]
         L.tso_reward.argtypes = [DP, SP, P]
         L.tso_generate.argtypes = [DP, SP, C.c_uint64, C.c_int64, C.c_int32]
+        L.tso_generate_mt19937.argtypes = [DP, SP, P, C.c_int32]
         L.tso_fill_actions.argtypes = [C.c_int64, C.c_uint64, C.c_int64, C.c_int64, P]
         _lib = L
     return _lib
@@ -245,6 +246,21 @@ def generate(size, n_tiles, n_targets, n_obstacles, n_boards, seed, board_offset
     dims = Dims(n_boards, size, n_tiles, n_targets, 0, 1, 0)
     st = State(None, _p(init), _p(tgt), _p(blk), None, None)
     rc = lib().tso_generate(C.byref(dims), C.byref(st), seed, board_offset, n_obstacles)
+    if rc != 0:
+        raise RuntimeError(f"oracle returned {rc}")
+    return blk, init, tgt
+
+
+def generate_mt19937(size, n_tiles, n_targets, n_obstacles, seeds):
+    """Twin of ts_generate_mt19937: the reference factory's level for each 32-bit seed."""
+    seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint32))
+    n = len(seeds)
+    blk = np.zeros((blk_words(size), n), np.uint32)
+    init = np.zeros((n_tiles, n), cell_dtype(size))
+    tgt = np.zeros((n_targets, n), cell_dtype(size))
+    dims = Dims(n, size, n_tiles, n_targets, 0, 1, 0)
+    st = State(None, _p(init), _p(tgt), _p(blk), None, None)
+    rc = lib().tso_generate_mt19937(C.byref(dims), C.byref(st), _p(seeds), n_obstacles)
     if rc != 0:
         raise RuntimeError(f"oracle returned {rc}")
     return blk, init, tgt

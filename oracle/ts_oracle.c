@@ -528,3 +528,74 @@ int32_t tso_fill_actions(int64_t N, uint64_t seed, int64_t board_offset, int64_t
     actions[n] = (uint8_t)(mix64(key + (uint64_t)(board_offset + n) * 0x9e3779b97f4a7c15ull) >> 62);
   return TS_OK;
 }
+
+/* The reference's own random levels (environment.py:217-226): np.random.seed(seed);
+ * np.random.shuffle(row-major list of cells); slices K / T / Tt.  numpy is a third-party
+ * dependency absent from /root/reference (pinned 2.3.4, uv.lock:293-294); its legacy stream is
+ * restated from the published algorithm — Matsumoto & Nishimura's mt19937ar.c (init_genrand,
+ * genrand_int32) and numpy's random_interval (mask = smallest 2^k - 1 >= max, rejection) in the
+ * untyped-list branch of RandomState.shuffle (i = n-1 .. 1: swap x[i], x[j]).  Pinned by the
+ * three SURVEY.md §8c captures and against numpy itself in tests/test_mt19937_levels.py. */
+typedef struct { uint32_t mt[624]; int pos; } tso_mt;
+
+static void mt_seed(tso_mt *m, uint32_t s) {
+  for (int i = 0; i < 624; ++i) {
+    m->mt[i] = s;
+    s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(i + 1);
+  }
+  m->pos = 624;
+}
+
+static uint32_t mt_next(tso_mt *m) {
+  if (m->pos == 624) {
+    uint32_t *mt = m->mt;
+    int i;
+    for (i = 0; i < 624 - 397; ++i) {
+      uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+      mt[i] = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; i < 623; ++i) {
+      uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+      mt[i] = mt[i - 227] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    m->pos = 0;
+  }
+  uint32_t y = m->mt[m->pos++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+int32_t tso_generate_mt19937(const ts_dims *d, const ts_state *st, const uint32_t *seeds, int32_t K) {
+  int32_t rc = check_dims(d);
+  if (rc) return rc;
+  const int S = d->size, C = S * S, T = d->n_tiles, Tt = d->n_targets, W = (C + 31) / 32;
+  const int64_t N = d->n_boards;
+  if (K < 0 || K + T + Tt > C) return TS_ERR_DIMS;
+  if (N == 0) return TS_OK;
+  if (!st || !seeds || !st->blk || (T && !st->init) || (Tt && !st->tgt)) return TS_ERR_NULL;
+  uint32_t *blk = (uint32_t *)st->blk;
+  void *init = (void *)st->init, *tgt = (void *)st->tgt;
+#pragma omp parallel for schedule(static) num_threads(tso_num_threads())
+  for (int64_t n = 0; n < N; ++n) {
+    tso_mt m;
+    uint16_t perm[TSO_MAX_CELLS];
+    mt_seed(&m, seeds[n]);
+    for (int i = 0; i < C; ++i) perm[i] = (uint16_t)i;
+    for (int i = C - 1; i >= 1; --i) {
+      uint32_t mask = (uint32_t)i, j;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+      do { j = mt_next(&m) & mask; } while (j > (uint32_t)i);
+      uint16_t a = perm[i]; perm[i] = perm[j]; perm[j] = a;
+    }
+    for (int w = 0; w < W; ++w) blk[(int64_t)w * N + n] = 0;
+    for (int k = 0; k < K; ++k) blk[(int64_t)(perm[k] >> 5) * N + n] |= 1u << (perm[k] & 31);
+    for (int t = 0; t < T; ++t) cell_set(d, init, (int64_t)t * N + n, perm[K + t]);
+    for (int t = 0; t < Tt; ++t) cell_set(d, tgt, (int64_t)t * N + n, perm[K + T + t]);
+  }
+  return TS_OK;
+}

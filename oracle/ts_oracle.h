@@ -53,6 +53,8 @@ int32_t tso_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int
                      int32_t n_obstacles);
 int32_t tso_fill_actions(int64_t n_boards, uint64_t seed, int64_t board_offset, int64_t step_index,
                          uint8_t *actions);
+/* twin of ts_generate_mt19937: the reference factory's level for every seed (environment.py:217-226) */
+int32_t tso_generate_mt19937(const ts_dims *dims, const ts_state *st, const uint32_t *seeds, int32_t n_obstacles);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ MODE_STRICT, MODE_AUTORESET = 0, 1
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
            "ts_encode_u8", "ts_expand_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions",
-           "ts_lines_words", "ts_prepare")
+           "ts_lines_words", "ts_prepare", "ts_generate_mt19937")
 
 
 class Dims(C.Structure):
@@ -114,6 +114,7 @@ def lib():
                        ("ts_encode", [DP, SP, P, P]), ("ts_encode_u8", [DP, SP, P, P]),
                        ("ts_encode_onehot", [DP, SP, P, P]), ("ts_reward", [DP, SP, P, P]),
                        ("ts_generate", [DP, SP, C.c_uint64, C.c_int64, C.c_int32, P]),
+                       ("ts_generate_mt19937", [DP, SP, P, C.c_int32, P]),
                        ("ts_fill_actions", [C.c_int64, C.c_uint64, C.c_int64, C.c_int64, P, P]),
                        ("ts_expand_u8", [P, P, C.c_int64, P])):
         fn = getattr(L, name)

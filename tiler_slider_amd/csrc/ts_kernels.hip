@@ -53,6 +53,9 @@
 #ifndef TS_XCD_REMAP
 #define TS_XCD_REMAP 1
 #endif
+#ifndef TS_XCD_PIECE  // 0 = each XCD owns one contiguous eighth of the batch; P > 0 = pieces of P blocks, round-robin
+#define TS_XCD_PIECE 0
+#endif
 #ifndef TS_WAVES_PER_BLOCK
 #define TS_WAVES_PER_BLOCK 4
 #endif
@@ -61,6 +64,21 @@
 #endif
 #ifndef TS_LINES_LDS_PAD  // diagnostic: extra dynamic LDS per wave of k_lines (lowers the resident waves)
 #define TS_LINES_LDS_PAD 0
+#endif
+#ifndef TS_LINES_WAVES  // waves per block of k_lines
+#define TS_LINES_WAVES 4
+#endif
+#ifndef TS_SMALL_LDS_PAD  // diagnostic: extra dynamic LDS per wave of k_small
+#define TS_SMALL_LDS_PAD 0
+#endif
+// Launches whose output cannot stay in the Infinity Cache (the ones that use nontemporal stores):
+// waves per block and blocks per CU.  -1 = the measured policy (ooc_residency below), 0 = no bound
+// (as many as registers / LDS admit: round 1's behaviour), > 0 = forced (tools/variant_bench.py sweeps).
+#ifndef TS_OOC_WAVES
+#define TS_OOC_WAVES -1
+#endif
+#ifndef TS_OOC_BLOCKS
+#define TS_OOC_BLOCKS -1
 #endif
 #ifndef TS_FORCE_OBS_BOARDS  // diagnostic: 64 = round 1's one-pass observation image at every size
 #define TS_FORCE_OBS_BOARDS 0
@@ -203,7 +221,15 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 //     order every 128-B line of pos/tgt/blk would be read and partially written through all 8
 //     non-coherent L2s.
 __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks) {
-#if TS_XCD_REMAP
+#if TS_XCD_REMAP && TS_XCD_PIECE > 0
+  // pieces of TS_XCD_PIECE consecutive blocks per XCD, dealt round-robin: the eight write fronts
+  // stay within 8 * TS_XCD_PIECE blocks of each other
+  constexpr uint32_t P = TS_XCD_PIECE;
+  const uint32_t full = nblocks / (8u * P) * (8u * P);
+  if (bid >= full) return bid;
+  const uint32_t xcd = bid & 7u, k = bid >> 3;
+  return ((k / P) * 8u + xcd) * P + (k % P);
+#elif TS_XCD_REMAP
   const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 #else
@@ -968,7 +994,7 @@ constexpr int lines_record_words(bool wide) { return wide ? 128 : 32; }
 // Br[r] / Bc[c]: obstacles of row r / column c (bit i = i-th cell along the line); Tm[r]: targets of row r.
 
 template <bool WIDE, int TPL>
-__global__ __launch_bounds__(256) void k_lines(const KArgs a, const int S, const uint32_t invS) {
+__global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, const int S, const uint32_t invS) {
   using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
   constexpr int G = kLinesG, BPW = kLinesBPW;
   constexpr int R = WIDE ? 2 : 1;   // lines per lane
@@ -1288,6 +1314,82 @@ __global__ __launch_bounds__(256) void k_generate(uint32_t *blk, cell_t *init, c
   for (int w = 0; w < W; ++w) blk[(int64_t)w * N + n] = blocked[w];
 }
 
+// The reference's own random levels, one board per seed, bit for bit:
+//   TilerSliderEnvFactory.create_simple_env (ref: explainrl/environment/environment.py:217-226)
+//   = np.random.seed(seed); np.random.shuffle(list of all (r, c) in row-major order);
+//     cells[:K] obstacles, cells[K:K+T] tiles, cells[K+T:K+T+Tt] targets.
+// The arithmetic lives in numpy (pinned: numpy 2.3.4, uv.lock:293-294; the legacy RandomState
+// stream is frozen across versions), restated here from its published algorithm:
+//   seed   : MT19937 init_genrand      mt[0] = seed, mt[i] = 1812433253 * (mt[i-1] ^ mt[i-1] >> 30) + i
+//   draw   : genrand_int32             (block twist of 624 words, then the tempering shifts)
+//   shuffle: for i = n-1 .. 1: j = random_interval(i); swap(x[i], x[j])            (untyped-list path)
+//   random_interval(max): mask = smallest 2^k - 1 >= max; draw 32 bits & mask until <= max
+// One thread per seed; the 624-word state and the cell list live in scratch memory (a level is
+// generated once per episode set, this is not the hot path).  Pinned by the three captures of
+// SURVEY.md §8c and by numpy itself in tests/ (numpy is importable wherever the tests run).
+__global__ __launch_bounds__(64) void k_generate_mt19937(uint32_t *blk, void *init_v, void *tgt_v, const uint32_t *seeds, int64_t N,
+                                                          int S, int T, int Tt, int K, int wide) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  constexpr int kN = 624, kM = 397;
+  uint32_t mt[kN];
+  uint16_t perm[TS_MAX_SIZE * TS_MAX_SIZE];
+  const int C = S * S, W = (C + 31) >> 5;
+  uint32_t x = seeds[n];
+  for (int i = 0; i < kN; ++i) {
+    mt[i] = x;
+    x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1);
+  }
+  int pos = kN;
+  auto next32 = [&]() -> uint32_t {
+    if (pos == kN) {  // refill: the standard block twist
+      auto tw = [](uint32_t u, uint32_t v) -> uint32_t { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
+      int i = 0;
+      for (; i < kN - kM; ++i) mt[i] = mt[i + kM] ^ tw(mt[i], mt[i + 1]);
+      for (; i < kN - 1; ++i) mt[i] = mt[i + (kM - kN)] ^ tw(mt[i], mt[i + 1]);
+      mt[kN - 1] = mt[kM - 1] ^ tw(mt[kN - 1], mt[0]);
+      pos = 0;
+    }
+    uint32_t y = mt[pos++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+  };
+  for (int i = 0; i < C; ++i) perm[i] = (uint16_t)i;
+  for (int i = C - 1; i >= 1; --i) {
+    uint32_t mask = (uint32_t)i;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t j;
+    do {
+      j = next32() & mask;
+    } while (j > (uint32_t)i);
+    const uint16_t a = perm[i];
+    perm[i] = perm[j];
+    perm[j] = a;
+  }
+  for (int w = 0; w < W; ++w) {  // obstacle words: OR of the first K cells that fall into word w
+    uint32_t bits = 0;
+    for (int k = 0; k < K; ++k)
+      if ((perm[k] >> 5) == w) bits |= 1u << (perm[k] & 31);
+    blk[(int64_t)w * N + n] = bits;
+  }
+  if (wide) {
+    uint16_t *init = static_cast<uint16_t *>(init_v), *tgt = static_cast<uint16_t *>(tgt_v);
+    for (int t = 0; t < T; ++t) init[(int64_t)t * N + n] = perm[K + t];
+    for (int t = 0; t < Tt; ++t) tgt[(int64_t)t * N + n] = perm[K + T + t];
+  } else {
+    uint8_t *init = static_cast<uint8_t *>(init_v), *tgt = static_cast<uint8_t *>(tgt_v);
+    for (int t = 0; t < T; ++t) init[(int64_t)t * N + n] = (uint8_t)perm[K + t];
+    for (int t = 0; t < Tt; ++t) tgt[(int64_t)t * N + n] = (uint8_t)perm[K + T + t];
+  }
+}
+
 // uint8 -> float32, 16 output bytes per lane, one KiB per wave, workgroups in address order: the
 // dense linearly advancing write front that reaches 6.8-7.1 TB/s beyond the Infinity Cache.
 template <bool NT>
@@ -1390,6 +1492,39 @@ size_t device_block_lds_limit() {
   return cached;
 }
 
+// Dynamic LDS request that admits exactly `blocks_per_cu` blocks on a CU: floor(cu_lds / request)
+// == blocks_per_cu.  `need` is what the block really uses; returns `need` when that alone already
+// admits fewer.  (LDS is the only per-launch occupancy control a plain launch has.)
+size_t lds_request_for_blocks_per_cu(size_t need, int blocks_per_cu) {
+  if (blocks_per_cu <= 0) return need;
+  const size_t cu_lds = 160u * 1024u;
+  const size_t floor_req = (cu_lds / (size_t)(blocks_per_cu + 1) + 16u) & ~(size_t)15u;  // just too big for one block more
+  return need > floor_req ? need : floor_req;
+}
+
+// Resident waves per CU for launches beyond the Infinity Cache.  Every wave streams one
+// contiguous chunk of output (`chunk` bytes: its boards' observations, plus one-hot planes); the
+// fewer waves are resident, the narrower the band of addresses the chip writes at any moment,
+// and HBM write efficiency follows that band (profiles/r01_membench_*: 1 KiB per wave 6.8 TB/s,
+// 12 KiB per wave 5.4 TB/s at full occupancy) — until too few waves are left to hide the state
+// loads.  Sweep of waves-per-block x blocks-per-CU over eleven shapes
+// (profiles/r02_ooc_residency_sweep.log): blocks of ONE wave (finest dispatch granularity) and
+// 7-12 resident waves per CU win by 5-16 % (cfg4 146.8 -> 123.6 us, 12x12 80.4 -> 68.3, 4x4 at
+// 4M boards 140.7 -> 132.1, cfg2 151.8 -> 139.9); kernels with long per-board arithmetic (the
+// any-tile-count path of k_small) need the full occupancy and are left alone.
+struct Residency {
+  int waves_per_block;  // 0 = keep the kernel's default
+  int blocks_per_cu;    // 0 = unbounded
+};
+Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy, uint64_t chunk) {
+  if (!out_of_cache || TS_OOC_WAVES == 0) return {0, 0};
+  if (TS_OOC_WAVES > 0) return {TS_OOC_WAVES, TS_OOC_BLOCKS > 0 ? TS_OOC_BLOCKS : 0};
+  if (compute_heavy) return {0, 0};
+  if (chunk >= 40u * 1024u) return {1, 4};
+  if (lines_kernel) return {1, chunk < 5u * 1024u ? 12 : chunk < 8u * 1024u ? 10 : 7};
+  return {1, 10};
+}
+
 int32_t finish_launch() {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1436,20 +1571,23 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const bool need_stage = tfix == 0 || (a.onehot && !a.oh_boards);
     a.lds_stage_off = align16((uint32_t)(small_obs_boards(C) * 3 * C));
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
-    a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C));
-    int waves = TS_WAVES_PER_BLOCK;
+    a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
+    const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);
+    const Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)kWave * out_per_board);
+    int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
     if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
     if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
+    const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
     const int64_t boards_per_block = (int64_t)waves * kWave;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
     const bool extras = a.valid || a.reward || a.onehot;
     SmallKernel k = extras ? small_kernel<true>(S, tfix) : small_kernel<false>(S, tfix);
 #if TS_SET_LDS_ATTR
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)waves * a.lds_wave_bytes));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
 #endif
-    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a);
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a);
   } else if (st->lines && !a.valid && !a.reward && !a.onehot && TS_USE_LINES) {
     // plain step / reset / encode with the level's precomputed line masks: k_lines
     const bool wide = S > 16;
@@ -1459,9 +1597,11 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     while (tpl < per_lane) tpl <<= 1;
     a.lds_stage_off = align16((uint32_t)(kLinesBPW * 3 * C));
     a.lds_wave_bytes = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) + TS_LINES_LDS_PAD;
-    const int waves = 4;
+    const Residency res = ooc_residency(a.nt != 0, true, false, (uint64_t)kLinesBPW * (a.obs ? 12ull * C : 0ull));
+    const int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
     if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
+    const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
     const int64_t boards_per_block = (int64_t)waves * kLinesBPW;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
@@ -1475,7 +1615,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
       case 8: k = wide ? k_lines<true, 8> : k_lines<false, 8>; break;
       default: k = wide ? k_lines<true, 16> : k_lines<false, 16>; break;
     }
-    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, inv_s);
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a, S, inv_s);
   } else {
     const bool wide = S > 16;
     const uint32_t mask_bytes = wide ? (uint32_t)sizeof(LineMasks<32>) : (uint32_t)sizeof(LineMasks<16>);
@@ -1703,6 +1843,21 @@ int32_t ts_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int6
     hipLaunchKernelGGL(k_generate<uint16_t>, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t *)st->blk,
                        (uint16_t *)st->init, (uint16_t *)st->tgt, dims->n_boards, dims->size, dims->n_tiles, dims->n_targets,
                        n_obstacles, seed, board_offset);
+  return finish_launch();
+}
+
+int32_t ts_generate_mt19937(const ts_dims *dims, const ts_state *st, const uint32_t *seeds, int32_t n_obstacles, void *stream) {
+  const int32_t rc = check_dims(dims);
+  if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;
+  const int C = dims->size * dims->size;
+  if (n_obstacles < 0 || n_obstacles + dims->n_tiles + dims->n_targets > C) return TS_ERR_DIMS;
+  if (!st || !seeds || !st->blk || (dims->n_tiles && !st->init) || (dims->n_targets && !st->tgt)) return TS_ERR_NULL;
+  const int64_t blocks = (dims->n_boards + 63) / 64;
+  if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
+  hipLaunchKernelGGL(k_generate_mt19937, dim3((uint32_t)blocks), dim3(64), 0, (hipStream_t)stream, (uint32_t *)st->blk,
+                     const_cast<void *>(st->init), const_cast<void *>(st->tgt), seeds, dims->n_boards, dims->size, dims->n_tiles,
+                     dims->n_targets, n_obstacles, dims->size > 16 ? 1 : 0);
   return finish_launch();
 }
 

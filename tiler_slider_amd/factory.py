@@ -45,7 +45,9 @@ class TilerSliderEnvFactory:
 
     @staticmethod
     def create_vec_env_from_seeds(seeds, size=5, num_tiles=2, num_obstacles=3, max_steps=100, **kw):
-        """One board per seed, each exactly the reference's create_simple_env(seed) level."""
-        levels = [simple_level(size, num_tiles, num_obstacles, int(s)) for s in seeds]
-        return VecTilerSliderEnv(size, [l[0] for l in levels], [l[1] for l in levels], [l[2] for l in levels],
-                                 multi_color=False, max_steps=max_steps, **kw)
+        """One board per seed, each exactly the reference's create_simple_env(seed) level
+        (environment.py:202-234: multi_color=False, max_steps=100), generated ON THE DEVICE by
+        ts_generate_mt19937 — numpy's legacy MT19937 stream and list shuffle restated in HIP, one
+        thread per seed.  `seeds`: integers in 0..2**32-1 (any sequence, numpy array or tensor)."""
+        return VecTilerSliderEnv.from_seeds(seeds, size=size, num_tiles=num_tiles, num_obstacles=num_obstacles,
+                                            multi_color=kw.pop("multi_color", False), max_steps=max_steps, **kw)

@@ -166,11 +166,39 @@ class VecTilerSliderEnv:
         init = torch.zeros((num_tiles, n_boards), dtype=_cell_torch_dtype(size), device=device)
         tgt = torch.zeros((num_tiles, n_boards), dtype=_cell_torch_dtype(size), device=device)
         dims = _cabi.Dims(n_boards, size, num_tiles, num_tiles, int(bool(multi_color)), max_steps, 0)
-        st = _cabi.State(None, init.data_ptr(), tgt.data_ptr(), blk.data_ptr(), None, None)
+        st = _cabi.State(None, init.data_ptr(), tgt.data_ptr(), blk.data_ptr(), None, None, None)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _cabi.check(_cabi.lib().ts_generate(C.byref(dims), C.byref(st), C.c_uint64(seed & (2**64 - 1)),
                                                 board_offset, num_obstacles, stream), "ts_generate")
+        return cls.from_arrays(size, blk, init, tgt, multi_color=multi_color, max_steps=max_steps, **kw)
+
+    @classmethod
+    def from_seeds(cls, seeds, size=5, num_tiles=2, num_obstacles=3, multi_color=False, max_steps=100, **kw):
+        """One board per seed: the level TilerSliderEnvFactory.create_simple_env(size, num_tiles,
+        num_obstacles, seed) of the reference builds (ref: environment.py:217-226), bit for bit,
+        generated on the device (include/tiler_slider.h: ts_generate_mt19937)."""
+        device = _resolve_device(kw.get("device"))
+        if isinstance(seeds, torch.Tensor):
+            sd = seeds.detach().to("cpu", torch.int64).numpy()
+        else:
+            sd = np.asarray(seeds, dtype=np.int64 if not isinstance(seeds, np.ndarray) or seeds.dtype.kind == "i" else seeds.dtype)
+        sd = sd.astype(np.int64).reshape(-1)
+        if sd.size and (sd.min() < 0 or sd.max() > 2**32 - 1):
+            raise ValueError("Seed must be between 0 and 2**32 - 1")  # numpy's own message for np.random.seed
+        n_boards = int(sd.size)
+        seeds_dev = torch.from_numpy(sd.astype(np.uint32).view(np.int32)).to(device)
+        W = blk_words(size)
+        blk = torch.zeros((W, n_boards), dtype=torch.int32, device=device)
+        init = torch.zeros((num_tiles, n_boards), dtype=_cell_torch_dtype(size), device=device)
+        tgt = torch.zeros((num_tiles, n_boards), dtype=_cell_torch_dtype(size), device=device)
+        dims = _cabi.Dims(n_boards, size, num_tiles, num_tiles, int(bool(multi_color)), max_steps, 0)
+        st = _cabi.State(None, init.data_ptr() if init.numel() else None, tgt.data_ptr() if tgt.numel() else None,
+                         blk.data_ptr() if blk.numel() else None, None, None, None)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _cabi.check(_cabi.lib().ts_generate_mt19937(C.byref(dims), C.byref(st), seeds_dev.data_ptr() if n_boards else None,
+                                                        num_obstacles, stream), "ts_generate_mt19937")
         return cls.from_arrays(size, blk, init, tgt, multi_color=multi_color, max_steps=max_steps, **kw)
 
     # ------------------------------------------------------------------ setup

@@ -55,9 +55,12 @@ def run(a):
         cfg["boards"] = a.boards
     n = cfg["boards"]
     dev = torch.device("cuda", 0)
-    env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
-                                   seed=bench.LEVEL_SEED, multi_color=True, max_steps=2**30, device=dev,
-                                   auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"])
+    keep = []  # --placement K: the K-th allocation of the environment (earlier ones stay alive), since
+    for _ in range(a.placement + 1):  # the step time depends on where the buffers landed (tools/placement_study.py)
+        env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
+                                       seed=bench.LEVEL_SEED, multi_color=True, max_steps=2**30, device=dev,
+                                       auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"])
+        keep.append(env)
     env.reset()
     stream = torch.cuda.current_stream(dev).cuda_stream
     ring = []
@@ -133,5 +136,6 @@ if __name__ == "__main__":
     r.add_argument("--shape", help="S,T,K,N: ad-hoc shape registered under --config's name")
     r.add_argument("--no-check", action="store_true")
     r.add_argument("--tag", default="")
+    r.add_argument("--placement", type=int, default=0, help="use the K-th allocation of the environment")
     args = ap.parse_args()
     build(args.specs) if args.cmd == "build" else run(args)
