@@ -39,6 +39,18 @@ def main():
             lines.append(f"| `{r['Name'][:90]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | "
                          f"{float(r['MinNs']) / 1e3:.2f} | {float(r['MaxNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} |")
         lines.append("")
+        traces = glob.glob(os.path.join(a.stats, "**", "*kernel_trace.csv"), recursive=True)
+        if traces:
+            per = collections.defaultdict(list)
+            for r in csv.DictReader(open(traces[0])):
+                name = (re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"]) or [r["Kernel_Name"][:60]])[0]
+                per[(name, r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")), r.get("LDS_Block_Size", ""))].append(
+                    (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            lines += ["## the same trace by (kernel, grid): one bench run launches the headline kernel at more than one batch size",
+                      "", "| kernel | grid (threads) | block | LDS/block | launches | avg us | min us | max us |", "|---|---|---|---|---|---|---|---|"]
+            for (name, grid, wg, lds), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                lines.append(f"| `{name}` | {grid} | {wg} | {lds} | {len(v)} | {sum(v) / len(v):.2f} | {min(v):.2f} | {max(v):.2f} |")
+            lines.append("")
     for d in a.pmc:
         f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
         agg = collections.defaultdict(list)

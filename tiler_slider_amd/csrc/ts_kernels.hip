@@ -30,7 +30,7 @@
 // Tunables (defaults are the shipped configuration; tools/variant_bench.py builds A/B variants
 // by overriding them with -D).
 #ifndef TS_EMIT_UNROLL
-#define TS_EMIT_UNROLL 4
+#define TS_EMIT_UNROLL 8
 #endif
 #ifndef TS_NT_THRESHOLD_MB  // launches that write more than this use nontemporal stores
 #define TS_NT_THRESHOLD_MB 256
@@ -43,6 +43,9 @@
 #endif
 #ifndef TS_LARGE_GSHIFT  // log2(lanes per board) of k_large; -1 = chosen per launch
 #define TS_LARGE_GSHIFT -1
+#endif
+#ifndef TS_EMIT_PRIO  // s_setprio level while a wave streams its observation out (0 = unchanged)
+#define TS_EMIT_PRIO 0
 #endif
 #ifndef TS_ABLATE  // development only (tools/variant_bench.py): 1 = skip the observation stores
 #define TS_ABLATE 0
@@ -160,6 +163,9 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
   const int nf4 = nfl >> 2;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
   f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
+#if TS_EMIT_PRIO > 0
+  __builtin_amdgcn_s_setprio(TS_EMIT_PRIO);
+#endif
 #if TS_ABLATE == 1
   if (nfl == -12345)  // never true: keeps the code, drops the traffic
 #endif
