@@ -158,8 +158,11 @@ __device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
 }
 
 // Streams `nfl` bytes of an LDS byte image out as float32, 16 B per lane per instruction.
-// `dst` is 16-B aligned; img is 16-B aligned.
-__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane, bool nt) {
+// `dst` is 16-B aligned; img is 16-B aligned.  NT (nontemporal stores) is a template parameter in
+// k_small / k_lines — the cache-resident and the out-of-cache launch are different instantiations,
+// so a profile lists them as different kernels — and a run-time flag in k_large.
+template <bool NT>
+__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane) {
   const int nf4 = nfl >> 2;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
   f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
@@ -169,15 +172,19 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
 #if TS_ABLATE == 1
   if (nfl == -12345)  // never true: keeps the code, drops the traffic
 #endif
-  if (nt) {
+  {
 #pragma unroll TS_EMIT_UNROLL
-    for (int q = lane; q < nf4; q += kWave) store_f4<true>(&d4[q], bytes_to_f4(w[q]));
-  } else {
-#pragma unroll TS_EMIT_UNROLL
-    for (int q = lane; q < nf4; q += kWave) store_f4<false>(&d4[q], bytes_to_f4(w[q]));
+    for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
   }
   const int tail = nfl & 3;  // only on the last, partial tile of odd-sized boards
   if (lane < tail) dst[nf4 * 4 + lane] = (float)img[nf4 * 4 + lane];
+}
+
+__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane, bool nt) {
+  if (nt)
+    emit_bytes_as_f32<true>(img, dst, nfl, lane);
+  else
+    emit_bytes_as_f32<false>(img, dst, nfl, lane);
 }
 
 // Streams `nbytes` of an LDS byte image out unchanged (the uint8 observation).  VEC = 16 needs
@@ -250,7 +257,7 @@ constexpr int kSmallBatch = 8;  // global loads in flight per lane in the any-T 
 
 // EXTRAS = false compiles the optional outputs (legality mask, reward, one-hot) out, so the
 // plain step / reset / encode path does not carry their registers and code.
-template <int S, int TFIX, bool EXTRAS>
+template <int S, int TFIX, bool EXTRAS, bool NT>
 __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   using BB = ts::Bitboard<S>;
   using M = typename BB::mask_t;
@@ -345,10 +352,15 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
     }
 #endif
   } else {
-    for (int t0 = 0; t0 < T; t0 += kSmallBatch) {  // loads issued kSmallBatch at a time (see k_large)
+    // Loads go out kSmallBatch at a time, UNCONDITIONALLY: lanes past the batch read the last
+    // board, rows past the tile count read the last row (results unused).  With a predicate per
+    // load the compiler emitted a branch and an `s_waitcnt vmcnt(0)` after every single load —
+    // eight dependent memory round trips per batch instead of one.
+    const int64_t nl = live ? n : N - 1;
+    for (int t0 = 0; t0 < T; t0 += kSmallBatch) {
       int v[kSmallBatch];
 #pragma unroll
-      for (int u = 0; u < kSmallBatch; ++u) v[u] = (live && t0 + u < T) ? (int)src[(int64_t)(t0 + u) * N + n] : 0;
+      for (int u = 0; u < kSmallBatch; ++u) v[u] = (int)src[(int64_t)min(t0 + u, T - 1) * N + nl];
 #pragma unroll
       for (int u = 0; u < kSmallBatch; ++u) {
         if (t0 + u < T) {
@@ -382,10 +394,11 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       st_np[t * kWave + lane] = (unsigned char)qt;
       if (live && kind != 1) a.pos[(int64_t)t * N + n] = (uint8_t)qt;
     }
+    const int64_t nl = live ? n : N - 1;
     for (int j0 = 0; j0 < Tt; j0 += kSmallBatch) {
       int v[kSmallBatch];
 #pragma unroll
-      for (int u = 0; u < kSmallBatch; ++u) v[u] = (live && j0 + u < Tt) ? (int)a.tgt[(int64_t)(j0 + u) * N + n] : 0;
+      for (int u = 0; u < kSmallBatch; ++u) v[u] = (int)a.tgt[(int64_t)min(j0 + u, Tt - 1) * N + nl];
 #pragma unroll
       for (int u = 0; u < kSmallBatch; ++u) {
         const int j = j0 + u;
@@ -522,7 +535,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
-      if (a.obs) emit_bytes_as_f32(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.nt != 0);
+      if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
       if (a.obs_u8) emit_bytes_raw<16>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
     }
   }
@@ -555,7 +568,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < nbc ? (nb - c0) : nbc;
-      emit_bytes_as_f32(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.nt != 0);
+      emit_bytes_as_f32<NT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane);
     }
   } else if (EXTRAS && a.onehot) {
     // Fallback for very many planes (one board's image above the LDS budget): every output
@@ -591,10 +604,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
           ++bb;
         }
       }
-      if (a.nt)
-        store_f4<true>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
-      else
-        store_f4<false>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
+      store_f4<NT>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
       r += 4 * kWave;
       while (r >= D) {
         r -= D;
@@ -999,7 +1009,7 @@ constexpr int lines_record_words(bool wide) { return wide ? 128 : 32; }
 //   S  > 16: w[j] = Br[j], w[32 + j] = Bc[j], w[64 + j] = Tm[j] (j < 32)   bit 0 of w[96]: duplicate targets
 // Br[r] / Bc[c]: obstacles of row r / column c (bit i = i-th cell along the line); Tm[r]: targets of row r.
 
-template <bool WIDE, int TPL>
+template <bool WIDE, int TPL, bool NT>
 __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, const int S, const uint32_t invS) {
   using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
   constexpr int G = kLinesG, BPW = kLinesBPW;
@@ -1215,7 +1225,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
       }
     }
     wave_sync();
-    if (a.obs) emit_bytes_as_f32(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.nt != 0);
+    if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
     if (a.obs_u8) emit_bytes_raw<4>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 }
@@ -1432,37 +1442,37 @@ int32_t onehot_channels(const ts_dims *d) { return d->multi_color ? 1 + d->n_til
 
 using SmallKernel = void (*)(const KArgs);
 
-template <int TFIX, bool EXTRAS>
+template <int TFIX, bool EXTRAS, bool NT>
 SmallKernel small_kernel_for(int S) {
   switch (S) {
-    case 1: return k_small<1, TFIX, EXTRAS>;
-    case 2: return k_small<2, TFIX, EXTRAS>;
-    case 3: return k_small<3, TFIX, EXTRAS>;
-    case 4: return k_small<4, TFIX, EXTRAS>;
-    case 5: return k_small<5, TFIX, EXTRAS>;
-    case 6: return k_small<6, TFIX, EXTRAS>;
-    case 7: return k_small<7, TFIX, EXTRAS>;
-    case 8: return k_small<8, TFIX, EXTRAS>;
+    case 1: return k_small<1, TFIX, EXTRAS, NT>;
+    case 2: return k_small<2, TFIX, EXTRAS, NT>;
+    case 3: return k_small<3, TFIX, EXTRAS, NT>;
+    case 4: return k_small<4, TFIX, EXTRAS, NT>;
+    case 5: return k_small<5, TFIX, EXTRAS, NT>;
+    case 6: return k_small<6, TFIX, EXTRAS, NT>;
+    case 7: return k_small<7, TFIX, EXTRAS, NT>;
+    case 8: return k_small<8, TFIX, EXTRAS, NT>;
     default: return nullptr;
   }
 }
 
-template <bool EXTRAS>
+template <bool EXTRAS, bool NT>
 SmallKernel small_kernel(int S, int tfix) {
   switch (tfix) {
-    case 1: return small_kernel_for<1, EXTRAS>(S);
-    case 2: return small_kernel_for<2, EXTRAS>(S);
-    case 3: return small_kernel_for<3, EXTRAS>(S);
-    case 4: return small_kernel_for<4, EXTRAS>(S);
+    case 1: return small_kernel_for<1, EXTRAS, NT>(S);
+    case 2: return small_kernel_for<2, EXTRAS, NT>(S);
+    case 3: return small_kernel_for<3, EXTRAS, NT>(S);
+    case 4: return small_kernel_for<4, EXTRAS, NT>(S);
 #if TS_MAX_TFIX >= 6
-    case 5: return small_kernel_for<5, EXTRAS>(S);
-    case 6: return small_kernel_for<6, EXTRAS>(S);
+    case 5: return small_kernel_for<5, EXTRAS, NT>(S);
+    case 6: return small_kernel_for<6, EXTRAS, NT>(S);
 #endif
 #if TS_MAX_TFIX >= 8
-    case 7: return small_kernel_for<7, EXTRAS>(S);
-    case 8: return small_kernel_for<8, EXTRAS>(S);
+    case 7: return small_kernel_for<7, EXTRAS, NT>(S);
+    case 8: return small_kernel_for<8, EXTRAS, NT>(S);
 #endif
-    default: return small_kernel_for<0, EXTRAS>(S);
+    default: return small_kernel_for<0, EXTRAS, NT>(S);
   }
 }
 
@@ -1589,7 +1599,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
     const bool extras = a.valid || a.reward || a.onehot;
-    SmallKernel k = extras ? small_kernel<true>(S, tfix) : small_kernel<false>(S, tfix);
+    SmallKernel k = extras ? (a.nt ? small_kernel<true, true>(S, tfix) : small_kernel<true, false>(S, tfix))
+                           : (a.nt ? small_kernel<false, true>(S, tfix) : small_kernel<false, false>(S, tfix));
 #if TS_SET_LDS_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
 #endif
@@ -1614,12 +1625,17 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const uint32_t inv_s = (uint32_t)((65536 + S - 1) / S);
     using LinesKernel = void (*)(const KArgs, const int, const uint32_t);
     LinesKernel k = nullptr;
+    auto pick = [&](auto tpl_c) -> LinesKernel {
+      constexpr int TPLC = decltype(tpl_c)::value;
+      return wide ? (a.nt ? k_lines<true, TPLC, true> : k_lines<true, TPLC, false>)
+                  : (a.nt ? k_lines<false, TPLC, true> : k_lines<false, TPLC, false>);
+    };
     switch (tpl) {
-      case 1: k = wide ? k_lines<true, 1> : k_lines<false, 1>; break;
-      case 2: k = wide ? k_lines<true, 2> : k_lines<false, 2>; break;
-      case 4: k = wide ? k_lines<true, 4> : k_lines<false, 4>; break;
-      case 8: k = wide ? k_lines<true, 8> : k_lines<false, 8>; break;
-      default: k = wide ? k_lines<true, 16> : k_lines<false, 16>; break;
+      case 1: k = pick(std::integral_constant<int, 1>{}); break;
+      case 2: k = pick(std::integral_constant<int, 2>{}); break;
+      case 4: k = pick(std::integral_constant<int, 4>{}); break;
+      case 8: k = pick(std::integral_constant<int, 8>{}); break;
+      default: k = pick(std::integral_constant<int, 16>{}); break;
     }
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a, S, inv_s);
   } else {
