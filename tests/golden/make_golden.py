@@ -5,10 +5,8 @@ Runs only in the build container (needs /root/reference); the GPU box and the te
 suite read the committed .npz files and never this script's imports.
 
 What is imported: explainrl/environment/state.py, loaded by file path.  It depends on
-numpy, copy and enum only.  explainrl/environment/environment.py is NOT imported (its
-package __init__ pulls cv2 / pygame, absent here, and no stand-ins are written for
-them); the wrapper logic of step()/reset() is pinned by the values asserted in the
-reference's own tests instead (tests/test_reference_known_answers.py).
+numpy, copy and enum only.  The wrapper (explainrl/environment/environment.py) is covered by
+the sibling script make_env_golden.py -> ref_env_*.npz.
 
 Each .npz holds one "group" = boards of one shape (S, T, Tt, multi_color):
   size, n_tiles, n_targets, multi_color   scalars

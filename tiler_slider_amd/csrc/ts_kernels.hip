@@ -44,6 +44,9 @@
 #ifndef TS_LARGE_GSHIFT  // log2(lanes per board) of k_large; -1 = chosen per launch
 #define TS_LARGE_GSHIFT -1
 #endif
+#ifndef TS_EMIT_WAIT_EVERY  // experiment: s_waitcnt vmcnt(0) after every N observation stores of a wave (0 = never)
+#define TS_EMIT_WAIT_EVERY 0
+#endif
 #ifndef TS_EMIT_PRIO  // s_setprio level while a wave streams its observation out (0 = unchanged)
 #define TS_EMIT_PRIO 0
 #endif
@@ -173,8 +176,20 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
   if (nfl == -12345)  // never true: keeps the code, drops the traffic
 #endif
   {
+#if TS_EMIT_WAIT_EVERY > 0
+    // experiment: at most TS_EMIT_WAIT_EVERY KiB of this wave's observation stores in flight
+    int issued = 0;
+    for (int q = lane; q < nf4; q += kWave) {
+      store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+      if (++issued == TS_EMIT_WAIT_EVERY) {
+        issued = 0;
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only (gfx9 encoding: expcnt 7, lgkmcnt 15)
+      }
+    }
+#else
 #pragma unroll TS_EMIT_UNROLL
     for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+#endif
   }
   const int tail = nfl & 3;  // only on the last, partial tile of odd-sized boards
   if (lane < tail) dst[nf4 * 4 + lane] = (float)img[nf4 * 4 + lane];
