@@ -1024,7 +1024,7 @@ constexpr int lines_record_words(bool wide) { return wide ? 128 : 32; }
 //   S  > 16: w[j] = Br[j], w[32 + j] = Bc[j], w[64 + j] = Tm[j] (j < 32)   bit 0 of w[96]: duplicate targets
 // Br[r] / Bc[c]: obstacles of row r / column c (bit i = i-th cell along the line); Tm[r]: targets of row r.
 
-template <bool WIDE, int TPL, bool NT>
+template <bool WIDE, int TPL, bool NT, bool EXTRAS>
 __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, const int S, const uint32_t invS) {
   using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
   constexpr int G = kLinesG, BPW = kLinesBPW;
@@ -1054,7 +1054,8 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;          // [BPW][3C] bytes, flat
   uint32_t *lnB = reinterpret_cast<uint32_t *>(img + a.lds_stage_off);  // obstacle line masks [BPW][NL] (x2 when WIDE)
   uint32_t *occ = lnB + BPW * NL * R;                                   // pre-move tiles along the move's lines
-  uint32_t *nrw = occ + BPW * NL;                                       // post-move tiles by row (single colour only)
+  uint32_t *nrw = occ + BPW * NL;                                       // post-move tiles by row (set-equality win test, legality mask)
+  uint16_t *tcells = reinterpret_cast<uint16_t *>(nrw + BPW * NL);      // EXTRAS, single-colour reward: target cells [BPW][Tt]
   const int lb = g * NL;
 
   // ---- loads ----
@@ -1150,6 +1151,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   bool same = true, ordered = true;
   cell_t *pos_out = reinterpret_cast<cell_t *>(a.pos) + off0;
   const bool store_pos = live && kind != 1;
+  const bool need_rows = !mc || (EXTRAS && a.valid != nullptr);  // post-move row masks
 #pragma unroll
   for (int k = 0; k < TPL; ++k) {
     const int line = vert ? pc[k] : pr[k];
@@ -1168,13 +1170,15 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
     const int q = mul_s(r) + c;
     same &= (q == p[k]) | !hasT[k];
     ordered &= (q == tg[k]) | !(hasT[k] && hasG[k]);
-    if (!mc) atomicOr(&nrw[lb + r], hasT[k] ? 1u << c : 0u);
+    if (need_rows) atomicOr(&nrw[lb + r], hasT[k] ? 1u << c : 0u);
     if (store_pos && hasT[k]) pos_out[k * gs] = (cell_t)q;
     p[k] = q;
+    pr[k] = r;
+    pc[k] = c;
   }
   bool rows_equal = true;
+  if (need_rows) wave_sync();
   if (!mc) {
-    wave_sync();
 #pragma unroll
     for (int i = 0; i < R; ++i) rows_equal &= nrw[lb + j + i * G] == (WIDE ? wx[i] : (wx[i] & 0xffffu));
   }
@@ -1199,6 +1203,67 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
       a.done[n] = 0;
     }
     if (a.flags) a.flags[n] = (uint8_t)flags;
+  }
+
+  if constexpr (EXTRAS) {
+    // ---- legality mask of the post-move board (environment.py:149-171) ----
+    // A move changes the board iff some tile has a free cell next to it in that direction: in a
+    // packed run (the fixed point of the slide) the tile nearest the run's end touches an
+    // obstacle / the wall and every other tile touches a tile; conversely a tile with a free
+    // neighbour sits in a run that is not packed.  So four neighbour tests per tile replace four
+    // trial slides (k_large); tests/: every shape against the oracle's four trial moves.
+    if (a.valid) {
+      uint32_t mv = 0;
+#pragma unroll
+      for (int k = 0; k < TPL; ++k) {
+        const int r = pr[k], c = pc[k];
+        const uint32_t here = lnB[lb * R + r] | nrw[lb + r];  // obstacles | tiles of the tile's row (WIDE: row masks come first)
+        const uint32_t row_mask = WIDE ? here : ((lnB[lb + r] & 0xffffu) | nrw[lb + r]);
+        const int ru = max(r - 1, 0), rd = min(r + 1, S - 1);
+        const uint32_t up = WIDE ? (lnB[lb * R + ru] | nrw[lb + ru]) : ((lnB[lb + ru] & 0xffffu) | nrw[lb + ru]);
+        const uint32_t dn = WIDE ? (lnB[lb * R + rd] | nrw[lb + rd]) : ((lnB[lb + rd] & 0xffffu) | nrw[lb + rd]);
+        uint32_t m = 0;
+        m |= (r > 0 && !((up >> c) & 1u)) ? 1u : 0u;                          // UP
+        m |= (r < S - 1 && !((dn >> c) & 1u)) ? 2u : 0u;                      // DOWN
+        m |= (c > 0 && !((row_mask >> (c - 1)) & 1u)) ? 4u : 0u;              // LEFT   (c - 1 is only shifted by when c > 0)
+        m |= (c < S - 1 && !((row_mask >> (c + 1)) & 1u)) ? 8u : 0u;          // RIGHT
+        mv |= hasT[k] ? m : 0u;
+      }
+      uint32_t vm = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) vm |= ((__ballot((mv >> d) & 1u) & gmask) != 0 ? 1u : 0u) << d;
+      if (live && j == 0) a.valid[n] = (uint8_t)vm;
+    }
+    // ---- build-defined Manhattan reward (include/tiler_slider.h) ----
+    if (a.reward) {
+      int sum = 0;
+      if (mc) {
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+          const int tr = div_s(tg[k]), tc = tg[k] - mul_s(tr);
+          sum += (hasT[k] && hasG[k]) ? abs(pr[k] - tr) + abs(pc[k] - tc) : 0;
+        }
+      } else if (Tt > 0) {
+        uint16_t *tc0 = tcells + (size_t)g * Tt;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k)
+          if (hasG[k]) tc0[j + k * G] = (uint16_t)tg[k];
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+          int best = 1 << 30;
+          for (int t = 0; t < Tt; ++t) {
+            const int y = tc0[t];
+            const int yr = div_s(y), yc = y - mul_s(yr);
+            const int dist = abs(pr[k] - yr) + abs(pc[k] - yc);
+            best = dist < best ? dist : best;
+          }
+          sum += hasT[k] ? best : 0;
+        }
+      }
+      for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);  // stays inside the 16-lane group
+      if (live && j == 0) a.reward[n] = -sum;
+    }
   }
 
   // ---- observation (state.py:188-211) through the LDS byte image ----
@@ -1548,6 +1613,10 @@ struct Residency {
   int blocks_per_cu;    // 0 = unbounded
 };
 Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy, uint64_t chunk) {
+#if defined(TS_RES_ALWAYS)  // experiment: apply the forced residency to cache-resident launches too
+  (void)out_of_cache;
+  return {TS_OOC_WAVES, TS_OOC_BLOCKS};
+#endif
   if (!out_of_cache || TS_OOC_WAVES == 0) return {0, 0};
   if (TS_OOC_WAVES > 0) return {TS_OOC_WAVES, TS_OOC_BLOCKS > 0 ? TS_OOC_BLOCKS : 0};
   if (compute_heavy) return {0, 0};
@@ -1620,15 +1689,17 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
 #endif
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a);
-  } else if (st->lines && !a.valid && !a.reward && !a.onehot && TS_USE_LINES) {
-    // plain step / reset / encode with the level's precomputed line masks: k_lines
+  } else if (st->lines && !a.onehot && TS_USE_LINES) {
+    // step / reset / encode (+ legality mask, reward) with the level's precomputed line masks: k_lines
     const bool wide = S > 16;
     a.lines = st->lines;
     const int per_lane = ((T > Tt ? T : Tt) + kLinesG - 1) / kLinesG;
     int tpl = 1;
     while (tpl < per_lane) tpl <<= 1;
     a.lds_stage_off = align16((uint32_t)(kLinesBPW * 3 * C));
-    a.lds_wave_bytes = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) + TS_LINES_LDS_PAD;
+    const bool lines_extras = a.valid || a.reward;
+    a.lds_wave_bytes = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) +
+                       (lines_extras && a.reward && !d->multi_color ? align16((uint32_t)(kLinesBPW * Tt * 2)) : 0u) + TS_LINES_LDS_PAD;
     const Residency res = ooc_residency(a.nt != 0, true, false, (uint64_t)kLinesBPW * (a.obs ? 12ull * C : 0ull));
     const int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
@@ -1642,8 +1713,11 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     LinesKernel k = nullptr;
     auto pick = [&](auto tpl_c) -> LinesKernel {
       constexpr int TPLC = decltype(tpl_c)::value;
-      return wide ? (a.nt ? k_lines<true, TPLC, true> : k_lines<true, TPLC, false>)
-                  : (a.nt ? k_lines<false, TPLC, true> : k_lines<false, TPLC, false>);
+      if (lines_extras)
+        return wide ? (a.nt ? k_lines<true, TPLC, true, true> : k_lines<true, TPLC, false, true>)
+                    : (a.nt ? k_lines<false, TPLC, true, true> : k_lines<false, TPLC, false, true>);
+      return wide ? (a.nt ? k_lines<true, TPLC, true, false> : k_lines<true, TPLC, false, false>)
+                  : (a.nt ? k_lines<false, TPLC, true, false> : k_lines<false, TPLC, false, false>);
     };
     switch (tpl) {
       case 1: k = pick(std::integral_constant<int, 1>{}); break;

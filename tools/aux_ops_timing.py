@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Development tool: time every entry point of the C-ABI at the headline batch (cfg1)."""
+"""Development tool: time every entry point of the C-ABI at a bench config (default: the headline batch cfg1)."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,7 +17,8 @@ env.reset(); envx.reset()
 act = torch.randint(0, 4, (n,), dtype=torch.uint8, device=env.device)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 obs_buf = torch.empty_like(env._obs)
-oh_buf = torch.empty((n, env.onehot_channels, env.size, env.size), dtype=torch.float32, device=env.device)
+oh_bytes = n * env.onehot_channels * env.size ** 2 * 4
+oh_buf = torch.empty((n, env.onehot_channels, env.size, env.size), dtype=torch.float32, device=env.device) if oh_bytes < 4e9 else None
 r_buf = torch.empty(n, dtype=torch.int32, device=env.device)
 
 
@@ -40,5 +41,6 @@ for name, fn in (("ts_step (flags+obs)", lambda: env.step_async(act)),
                  ("ts_valid_moves", env.get_valid_moves),
                  ("ts_is_won", env.is_won),
                  ("ts_reward", lambda: env.reward(r_buf)),
-                 ("ts_encode_onehot", lambda: env.encode_onehot(oh_buf))):
-    print(f"  {name:34s} {t(fn):8.2f} us", flush=True)
+                 ("ts_encode_onehot", (lambda: env.encode_onehot(oh_buf)) if oh_buf is not None else None)):
+    if fn is not None:
+        print(f"  {name:34s} {t(fn):8.2f} us", flush=True)
