@@ -106,9 +106,20 @@ def cpu_baseline(cfg, budget_s=10.0):
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": int(orc.lib().tso_num_threads()),
             "kind": "port",
             "sample": f"{n} boards x {steps} steps of the same workload (oracle/ts_oracle.c, OpenMP), {dt:.1f} s",
-            "reference_python_recorded": {"value": 9.2e4, "unit": "env-steps/s", "cores": 1,
-                                          "note": "reference TilerSliderEnv.step loop, 4x4 T2 K2, timed in the "
-                                                  "build container (BASELINE.md §2); the reference cannot travel"}}
+            "reference_python_recorded": reference_python_recorded(cfg)}
+
+
+# The reference's own Python TilerSliderEnv.step loop on ONE core (it is single-threaded) of the build container
+# (Xeon 2.1 GHz, py3.10, numpy 2.2), tools/time_reference_python.py; the reference cannot travel to the GPU box, so
+# these are recorded constants, keyed by (size, tiles, obstacles).
+REFERENCE_PYTHON_STEPS_PER_S = {(3, 1, 0): 1.03e5, (4, 2, 2): 1.22e5, (5, 2, 3): 1.05e5, (15, 32, 24): 1.45e4}
+
+
+def reference_python_recorded(cfg):
+    v = REFERENCE_PYTHON_STEPS_PER_S.get((cfg["size"], cfg["tiles"], cfg["obstacles"]))
+    return {"value": v, "unit": "env-steps/s", "cores": 1,
+            "note": "reference TilerSliderEnv.step loop of this board shape, timed in the build container "
+                    "(tools/time_reference_python.py); the reference cannot travel to the GPU box"}
 
 
 def spawn_ranks(n):
