@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   uint32_t *occ = lnB + BPW * NL * R;                                   // pre-move tiles along the move's lines
   uint32_t *nrw = occ + BPW * NL;                                       // post-move tiles by row (set-equality win test, legality mask)
   uint16_t *tcells = reinterpret_cast<uint16_t *>(nrw + BPW * NL);      // EXTRAS, single-colour reward: target cells [BPW][Tt]
+  unsigned char *ohimg = img + a.lds_oh_off;                            // EXTRAS, one-hot: one piece of the wave's plane stream
   const int lb = g * NL;
 
   // ---- loads ----
@@ -1307,6 +1308,46 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
     wave_sync();
     if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
     if (a.obs_u8) emit_bytes_raw<4>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
+  }
+
+  // ---- build-defined one-hot planes [board][Ch][S][S] (include/tiler_slider.h) ----
+  // The wave's boards form one contiguous stream of nb * Ch * C floats, almost all zero.  It is cut
+  // into pieces of kOhPiece bytes (one byte per float); per piece: zero the LDS image, every lane
+  // drops the ones of its own row of obstacles, tiles and targets that fall into the piece, and
+  // the whole wave streams the piece out like the observation.
+  if constexpr (EXTRAS) {
+    if (a.onehot) {
+      constexpr int kOhPiece = 8192;
+      const int Ch = a.onehot_ch;
+      const int64_t D = (int64_t)Ch * C;          // floats per board
+      const int64_t total = (int64_t)nb * D;      // floats of this wave
+      const int64_t mine = (int64_t)g * D;        // where this lane's board starts in the stream
+      float *dst = a.onehot + n0 * D;
+      for (int64_t p0 = 0; p0 < total; p0 += kOhPiece) {
+        wave_sync();  // the previous piece has been read out
+        for (int off = lane * 16; off < kOhPiece; off += kWave * 16) *reinterpret_cast<uint4 *>(ohimg + off) = make_uint4(0, 0, 0, 0);
+        wave_sync();
+        auto drop = [&](int plane, int cell) {
+          const int64_t e = mine + (int64_t)plane * C + cell - p0;
+          if (e >= 0 && e < kOhPiece) ohimg[e] = 1;
+        };
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            const int row0 = mul_s(j + i * G);
+            for (uint32_t m = WIDE ? wB[i] : (wB[0] & 0xffffu); m; m &= m - 1) drop(0, row0 + ts::lsb(m));
+          }
+#pragma unroll
+          for (int k = 0; k < TPL; ++k) {
+            if (hasT[k]) drop(mc ? 1 + j + k * G : 1, p[k]);
+            if (hasG[k]) drop(mc ? 1 + T + j + k * G : 2, tg[k]);
+          }
+        }
+        wave_sync();
+        const int64_t left = total - p0;
+        emit_bytes_as_f32<NT>(ohimg, dst + p0, (int)(left < kOhPiece ? left : kOhPiece), lane);
+      }
+    }
   }
 }
 
@@ -1689,19 +1730,22 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
 #endif
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a);
-  } else if (st->lines && !a.onehot && TS_USE_LINES) {
-    // step / reset / encode (+ legality mask, reward) with the level's precomputed line masks: k_lines
+  } else if (st->lines && TS_USE_LINES) {
+    // step / reset / encode (+ legality mask, reward, one-hot) with the level's precomputed line masks: k_lines
     const bool wide = S > 16;
     a.lines = st->lines;
     const int per_lane = ((T > Tt ? T : Tt) + kLinesG - 1) / kLinesG;
     int tpl = 1;
     while (tpl < per_lane) tpl <<= 1;
     a.lds_stage_off = align16((uint32_t)(kLinesBPW * 3 * C));
-    const bool lines_extras = a.valid || a.reward;
-    a.lds_wave_bytes = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) +
-                       (lines_extras && a.reward && !d->multi_color ? align16((uint32_t)(kLinesBPW * Tt * 2)) : 0u) + TS_LINES_LDS_PAD;
-    const Residency res = ooc_residency(a.nt != 0, true, false, (uint64_t)kLinesBPW * (a.obs ? 12ull * C : 0ull));
-    const int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
+    const bool lines_extras = a.valid || a.reward || a.onehot;
+    a.lds_oh_off = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) +
+                   (a.reward && !d->multi_color ? align16((uint32_t)(kLinesBPW * Tt * 2)) : 0u);
+    a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
+    const Residency res = ooc_residency(a.nt != 0, true, false,
+                                        (uint64_t)kLinesBPW * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull)));
+    int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
+    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
     if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
     const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
