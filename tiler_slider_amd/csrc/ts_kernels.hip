@@ -303,18 +303,29 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   unsigned char *st_tg = st_np + (size_t)T * kWave;             // [Tt][64] target cells
   const bool need_stage = (TFIX == 0) || (EXTRAS && a.onehot != nullptr && a.oh_boards == 0);
 
-  // ---- per-board scalars ----
-  M blk = 0;
+  // ---- loads: all unconditional, all issued before the first one is consumed ----
+  // Lanes past the batch read the LAST board and write nothing.  (With `live ? load : default`
+  // the compiler emitted a branch per load and waited for `done` / `step_count` / `action` before
+  // it even issued the cell loads: three to four dependent memory round trips per wave.)
+  const int64_t nl = live ? n : N - 1;
+  constexpr M kFull = C == 64 ? ~M(0) : (M(1) << (C & 63)) - 1;
+  const M blk = load_blk<M>(a.blk, N, nl) & kFull;  // bits past the board would index outside the LDS image
+  const bool all_reset = a.op == OP_RESET;  // uniform
+  int p[TR], q[TR], tg[TR];
+  if constexpr (TFIX > 0) {
+    const uint8_t *cur = all_reset ? a.init : a.pos;  // boards that autoreset inside a step reload below (rare)
+#pragma unroll
+    for (int t = 0; t < TFIX; ++t) {
+      p[t] = (int)cur[(int64_t)t * N + nl];
+      tg[t] = (int)a.tgt[(int64_t)t * N + nl];
+    }
+  }
   uint32_t action = 0, done_in = 0;
   int32_t sc = 0;
-  constexpr M kFull = C == 64 ? ~M(0) : (M(1) << (C & 63)) - 1;
-  if (live) {
-    blk = load_blk<M>(a.blk, N, n) & kFull;  // bits past the board would index outside the LDS image
-    if (a.op == OP_STEP) {
-      done_in = a.done[n];
-      sc = a.step_count[n];
-      action = a.actions[n];
-    }
+  if (a.op == OP_STEP) {  // uniform
+    done_in = a.done[nl];
+    sc = a.step_count[nl];
+    action = a.actions[nl];
   }
   // kind: 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells
   int kind;
@@ -336,42 +347,23 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   const int dir = (int)(action & 3u);
 
   // ---- pass 1: pre-move cells and occupancy ----
-  int p[TR], q[TR], tg[TR];
   M occ = 0;
   if constexpr (TFIX > 0) {
-#if TS_EARLY_LOADS
-    // The current cells are loaded without waiting for `done` (which decides between pos and
-    // init): one dependent memory round trip less on the common path; only boards that are
-    // being reset (rare in a step, all in ts_reset) issue the second load.
-    const bool all_reset = a.op == OP_RESET;
+    if (kind == 2 && !all_reset) {
 #pragma unroll
-    for (int t = 0; t < TFIX; ++t) {
-      p[t] = (live && !all_reset) ? (int)a.pos[(int64_t)t * N + n] : t;
-      tg[t] = live ? min((int)a.tgt[(int64_t)t * N + n], C - 1) : t;
-    }
-    if (kind == 2 && live) {
-#pragma unroll
-      for (int t = 0; t < TFIX; ++t) p[t] = (int)a.init[(int64_t)t * N + n];
+      for (int t = 0; t < TFIX; ++t) p[t] = (int)a.init[(int64_t)t * N + nl];
     }
 #pragma unroll
     for (int t = 0; t < TFIX; ++t) {
       p[t] = min(p[t], C - 1);  // clamp: malformed ids stay in-board
+      tg[t] = min(tg[t], C - 1);
       occ |= M(1) << p[t];
     }
-#else
-#pragma unroll
-    for (int t = 0; t < TFIX; ++t) {
-      p[t] = live ? min((int)src[(int64_t)t * N + n], C - 1) : t;  // clamp: malformed ids stay in-board
-      tg[t] = live ? min((int)a.tgt[(int64_t)t * N + n], C - 1) : t;
-      occ |= M(1) << p[t];
-    }
-#endif
   } else {
     // Loads go out kSmallBatch at a time, UNCONDITIONALLY: lanes past the batch read the last
     // board, rows past the tile count read the last row (results unused).  With a predicate per
     // load the compiler emitted a branch and an `s_waitcnt vmcnt(0)` after every single load —
     // eight dependent memory round trips per batch instead of one.
-    const int64_t nl = live ? n : N - 1;
     for (int t0 = 0; t0 < T; t0 += kSmallBatch) {
       int v[kSmallBatch];
 #pragma unroll
@@ -409,7 +401,6 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       st_np[t * kWave + lane] = (unsigned char)qt;
       if (live && kind != 1) a.pos[(int64_t)t * N + n] = (uint8_t)qt;
     }
-    const int64_t nl = live ? n : N - 1;
     for (int j0 = 0; j0 < Tt; j0 += kSmallBatch) {
       int v[kSmallBatch];
 #pragma unroll
@@ -1643,17 +1634,19 @@ size_t lds_request_for_blocks_per_cu(size_t need, int blocks_per_cu) {
 // contiguous chunk of output (`chunk` bytes: its boards' observations, plus one-hot planes); the
 // fewer waves are resident, the narrower the band of addresses the chip writes at any moment,
 // and HBM write efficiency follows that band (profiles/r01_membench_*: 1 KiB per wave 6.8 TB/s,
-// 12 KiB per wave 5.4 TB/s at full occupancy) — until too few waves are left to hide the state
-// loads.  Sweep of waves-per-block x blocks-per-CU over eleven shapes
-// (profiles/r02_ooc_residency_sweep.log): blocks of ONE wave (finest dispatch granularity) and
-// 7-12 resident waves per CU win by 5-16 % (cfg4 146.8 -> 123.6 us, 12x12 80.4 -> 68.3, 4x4 at
-// 4M boards 140.7 -> 132.1, cfg2 151.8 -> 139.9); kernels with long per-board arithmetic (the
-// any-tile-count path of k_small) need the full occupancy and are left alone.
+// 12 KiB per wave 5.4 TB/s at full occupancy; profiles/r02_ooc_residency_sweep.log: the same
+// fill with one-wave blocks peaks where about 20-40 KiB per CU are in flight) — until too few
+// waves are left to hide the state loads.  Sweeps of waves-per-block x blocks-per-CU over some
+// twenty shapes (same log): blocks of ONE wave (finest dispatch granularity) and 3-16 resident
+// waves per CU, by chunk size, win by 5-16 % (cfg4 146.8 -> 123.6 us, 12x12 80.4 -> 68.3, 4x4 at
+// 4M boards 142 -> 121, cfg2 145 -> 135); kernels with long per-board arithmetic (the
+// any-tile-count path of k_small) need the full occupancy and are left alone; cache-resident
+// launches lose with any bound (33.1 -> 33.8+ us at cfg1).
 struct Residency {
   int waves_per_block;  // 0 = keep the kernel's default
   int blocks_per_cu;    // 0 = unbounded
 };
-Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy, uint64_t chunk) {
+Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy, uint64_t chunk, int tiles) {
 #if defined(TS_RES_ALWAYS)  // experiment: apply the forced residency to cache-resident launches too
   (void)out_of_cache;
   return {TS_OOC_WAVES, TS_OOC_BLOCKS};
@@ -1661,9 +1654,16 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
   if (!out_of_cache || TS_OOC_WAVES == 0) return {0, 0};
   if (TS_OOC_WAVES > 0) return {TS_OOC_WAVES, TS_OOC_BLOCKS > 0 ? TS_OOC_BLOCKS : 0};
   if (compute_heavy) return {0, 0};
-  if (chunk >= 40u * 1024u) return {1, 4};
-  if (lines_kernel) return {1, chunk < 5u * 1024u ? 12 : chunk < 8u * 1024u ? 10 : 7};
-  return {1, 10};
+  if (lines_kernel) {
+    if (chunk >= 40u * 1024u) return {1, 4};
+    return {1, chunk < 5u * 1024u ? 12 : chunk < 8u * 1024u ? 10 : 7};
+  }
+  // k_small (all of a wave's loads in flight at once): about 64 KiB of output owned by resident waves per CU
+  if (chunk >= 40u * 1024u) return {1, 3};                 // cfg2 (51 KB): 3 -> 135 us, 4 -> 138, unbounded 145
+  if (chunk >= 16u * 1024u) return {1, 4};                 // 5x5 .. 7x7: 4 wins by 5-6 %
+  if (chunk >= 8u * 1024u) return {1, tiles <= 2 ? 5 : 6};  // 4x4: 4M boards 5 -> 121 us, 10 -> 137, unbounded 142
+  if (chunk >= 4u * 1024u) return {1, 10};                 // 3x3
+  return {1, 16};                                          // 2x2, 1x1
 }
 
 int32_t finish_launch() {
@@ -1714,7 +1714,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);
-    const Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)kWave * out_per_board);
+    const Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)kWave * out_per_board, T);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
     if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
@@ -1743,7 +1743,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                    (a.reward && !d->multi_color ? align16((uint32_t)(kLinesBPW * Tt * 2)) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
     const Residency res = ooc_residency(a.nt != 0, true, false,
-                                        (uint64_t)kLinesBPW * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull)));
+                                        (uint64_t)kLinesBPW * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull)), T);
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
