@@ -106,9 +106,8 @@ typedef struct ts_state {
   const uint32_t *blk; /* [W][N]  is_blocked bitmask (level) */
   int32_t *step_count; /* [N] */
   uint8_t *done;       /* [N] */
-  const uint32_t *lines; /* [N][ts_lines_words(S)] optional (ABI v3): the level's line masks built by
-                            ts_prepare.  NULL = the kernels derive them from blk / tgt on every
-                            call (slower above 8x8; results identical). */
+  const uint32_t *lines; /* [N][ts_lines_words(S)] (ABI v3): the level's line masks built by ts_prepare.
+                            Required for S >= 9 (TS_ERR_NULL otherwise); unused, may be NULL, for S <= 8. */
 } ts_state;
 
 typedef struct ts_step_out {
@@ -202,7 +201,8 @@ int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void
  *                       bit 31 of w[16] set <=> two targets share a cell
  *   S  > 16 (128 words): w[j] = Br[j], w[32 + j] = Bc[j], w[64 + j] = Tm[j] (j < 32);
  *                       bit 0 of w[96] set <=> two targets share a cell; the rest 0
- * Call ts_prepare again whenever blk or tgt change.  Reads st->blk and st->tgt only. */
+ * Call ts_prepare again whenever blk or tgt change.  Reads st->blk and st->tgt only.  Every entry
+ * point that takes a ts_state needs st->lines for S >= 9 and returns TS_ERR_NULL without it. */
 int32_t ts_lines_words(int32_t size);
 int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, void *stream);
 

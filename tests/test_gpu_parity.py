@@ -535,26 +535,25 @@ def test_prepare_tables_match_numpy(torch_cuda, oracle, S, T, Tt, K, N):
     np.testing.assert_array_equal(got, _lines_record_numpy(S, blk, tgt))
 
 
-@pytest.mark.parametrize("S,T,K,mc,N", [(9, 4, 9, True, 1001), (15, 32, 24, True, 515), (15, 32, 24, False, 515),
-                                        (16, 17, 30, False, 130), (20, 6, 30, True, 67), (32, 64, 100, False, 35)])
-def test_without_tables_equals_with_tables(torch_cuda, oracle, S, T, K, mc, N):
-    """ts_state.lines = NULL (callers that never ran ts_prepare: k_large derives everything per
-    step) and the table-driven k_lines give the same boards, flags and observations."""
+def test_large_boards_need_the_prepared_tables(torch_cuda, oracle):
+    """Above 8x8 every entry point works from ts_state.lines (ts_prepare); without it the C-ABI
+    answers TS_ERR_NULL instead of launching anything.  Up to 8x8 the field is ignored."""
+    import ctypes as C
     torch = torch_cuda
-    from tiler_slider_amd import VecTilerSliderEnv
-    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=21)
-    tgt[1 if T > 1 else 0, ::5] = tgt[0, ::5]
-    a = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True)
-    b = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True)
-    b._state.lines = None
-    assert torch.equal(a.reset(), b.reset())
-    for step in range(12):
-        act = torch.from_numpy(oracle.fill_actions(N, seed=4, step_index=step))
-        oa, da, ia = a.step(act)
-        ob, db, ib = b.step(act)
-        assert torch.equal(oa, ob) and torch.equal(da, db) and torch.equal(ia["flags"], ib["flags"])
-        assert torch.equal(a.positions, b.positions) and torch.equal(a.step_count, b.step_count)
-    assert torch.equal(a.is_won(), b.is_won()) and torch.equal(a.encode(), b.encode())
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    blk, init, tgt = oracle.generate(12, 8, 8, 16, 100, seed=21)
+    env = VecTilerSliderEnv.from_arrays(12, blk, init, tgt, multi_color=True)
+    env.reset()
+    st = _cabi.State(env._state.pos, env._state.init, env._state.tgt, env._state.blk, env._state.step_count, env._state.done, None)
+    stream = torch.cuda.current_stream().cuda_stream
+    L = _cabi.lib()
+    act = torch.zeros(100, dtype=torch.uint8, device=env.device)
+    assert L.ts_step(C.byref(env._dims), C.byref(st), act.data_ptr(), 0, C.byref(env._out), stream) == _cabi.ERR_NULL
+    assert L.ts_reset(C.byref(env._dims), C.byref(st), env._obs.data_ptr(), stream) == _cabi.ERR_NULL
+    assert L.ts_encode(C.byref(env._dims), C.byref(st), env._obs.data_ptr(), stream) == _cabi.ERR_NULL
+    assert L.ts_step(C.byref(env._dims), C.byref(env._state), act.data_ptr(), 0, C.byref(env._out), stream) == _cabi.OK
+    small = VecTilerSliderEnv.random(64, size=5)
+    assert small._lines is None and small.reset().shape == (64, 5, 5, 3)
 
 
 # ------------------------------------------------------------------------------------------------

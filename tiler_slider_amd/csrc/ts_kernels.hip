@@ -11,8 +11,8 @@
 //   * S <= 8   (k_small): ONE BOARD PER LANE, the whole board as a 32/64-bit bitboard in a
 //     register; a wave owns 64 consecutive boards.  SoA state loads/stores are coalesced
 //     (lane n <-> board n).
-//   * S 9..32  (k_large): 4..16 LANES PER BOARD (chosen per launch), obstacle / tile line
-//     masks in LDS; uint16 cell ids above 16x16.
+//   * S 9..32  (k_lines): 16 LANES PER BOARD, tiles in registers, the level's obstacle / target
+//     line masks precomputed once (ts_prepare); uint16 cell ids above 16x16.
 //   * observation: each wave builds a byte image [boards][S*S*3] of its boards in LDS, then
 //     streams it out as float4 (one ds_read_b32 + 4 v_cvt_f32_ubyteN + one 16-B global
 //     store per lane): the LDS image is the transpose from "lane = board" to "lane = 16
@@ -41,9 +41,6 @@
 #ifndef TS_EARLY_LOADS
 #define TS_EARLY_LOADS 1
 #endif
-#ifndef TS_LARGE_GSHIFT  // log2(lanes per board) of k_large; -1 = chosen per launch
-#define TS_LARGE_GSHIFT -1
-#endif
 #ifndef TS_EMIT_WAIT_EVERY  // experiment: s_waitcnt vmcnt(0) after every N observation stores of a wave (0 = never)
 #define TS_EMIT_WAIT_EVERY 0
 #endif
@@ -64,9 +61,6 @@
 #endif
 #ifndef TS_WAVES_PER_BLOCK
 #define TS_WAVES_PER_BLOCK 4
-#endif
-#ifndef TS_USE_LINES  // 0 = ignore ts_state.lines (always k_large above 8x8): A/B against round 1's kernel
-#define TS_USE_LINES 1
 #endif
 #ifndef TS_LINES_LDS_PAD  // diagnostic: extra dynamic LDS per wave of k_lines (lowers the resident waves)
 #define TS_LINES_LDS_PAD 0
@@ -162,8 +156,8 @@ __device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
 
 // Streams `nfl` bytes of an LDS byte image out as float32, 16 B per lane per instruction.
 // `dst` is 16-B aligned; img is 16-B aligned.  NT (nontemporal stores) is a template parameter in
-// k_small / k_lines — the cache-resident and the out-of-cache launch are different instantiations,
-// so a profile lists them as different kernels — and a run-time flag in k_large.
+// k_small / k_lines: the cache-resident and the out-of-cache launch are different instantiations,
+// so a profile lists them as different kernels.
 template <bool NT>
 __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane) {
   const int nf4 = nfl >> 2;
@@ -195,16 +189,9 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
   if (lane < tail) dst[nf4 * 4 + lane] = (float)img[nf4 * 4 + lane];
 }
 
-__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane, bool nt) {
-  if (nt)
-    emit_bytes_as_f32<true>(img, dst, nfl, lane);
-  else
-    emit_bytes_as_f32<false>(img, dst, nfl, lane);
-}
-
 // Streams `nbytes` of an LDS byte image out unchanged (the uint8 observation).  VEC = 16 needs
 // dst 16-B aligned (k_small: a tile starts at a multiple of 32 boards); VEC = 4 needs 4-B
-// alignment (k_large: 3*S*S bytes per board times a multiple of 4 boards).
+// alignment (k_lines: 3*S*S bytes per board times a multiple of 4 boards).
 template <int VEC>
 __device__ __forceinline__ void emit_bytes_raw(const unsigned char *img, uint8_t *dst, int nbytes, int lane) {
   using vec_t = typename std::conditional<VEC == 16, uint4, uint32_t>::type;
@@ -245,7 +232,7 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 //   * output beyond the Infinity Cache: a fill kernel whose waves own 12 KiB chunks writes 708 MB
 //     at 5.4 TB/s in blockIdx order and at 5.9 TB/s XCD-contiguous (profiles/r01_membench_*):
 //     each XCD's L2 then drains one dense address range instead of 1/8 of every range;
-//   * k_large: a wave touches just 4..16 consecutive bytes of each SoA state row, so in blockIdx
+//   * k_lines: a wave touches just 4 consecutive bytes of each SoA state row, so in blockIdx
 //     order every 128-B line of pos/tgt/blk would be read and partially written through all 8
 //     non-coherent L2s.
 __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks) {
@@ -626,386 +613,26 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// k_large<WIDE>: S in 9..16 (WIDE = false, uint8 cell ids) and 17..32 (WIDE = true, uint16 cell
-// ids).  G = 2^gshift lanes cooperate on one board (64/G boards per wave); the host picks G.
-// Obstacles, tiles and targets are kept as line masks in LDS (one 32-bit word per row / per
-// column, bit i = i-th cell along the line); a tile's new index along its lane comes from
-// ts::slide_line on the lane's obstacle and tile masks.  Lanes of a group share the board's
-// tiles round-robin (tile t -> lane t mod G); masks are accumulated with LDS atomic OR;
-// group-wide AND/OR go through __ballot.
-// ------------------------------------------------------------------------------------------
-constexpr int kLoadBatch = 8;  // global loads in flight per lane in the tile / target loops
-
-template <int MAXS>
-struct LineMasks {
-  uint32_t Br[MAXS], Bc[MAXS];  // obstacles of row r / of column c
-  uint32_t O[MAXS];             // tiles before the move, along the move's lanes only (columns for
-                                // a vertical move, rows for a horizontal one)
-  uint32_t Nr[MAXS], Nc[MAXS];  // tiles after the move, rows / columns
-  uint32_t Tm[MAXS];            // targets, rows
-};
-
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_large(const KArgs a, const int S, const int gshift, const uint32_t invS) {
-  using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
-  using Masks = LineMasks<WIDE ? 32 : 16>;
-  constexpr int kWords = WIDE ? 32 : 8;  // packed obstacle words of one board
-  // x / S for x < S*S without the ~25-instruction runtime division: invS = ceil(65536 / S) makes
-  // (x * invS) >> 16 exact for S <= 32 (checked exhaustively; the error x / 65536 stays below 1/S).
-  auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
-  auto cell_of = [&](int r, int c) -> int { return (int)__umul24((uint32_t)r, (uint32_t)S) + c; };
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
-  const int G = 1 << gshift;     // lanes per board
-  const int BPW = kWave >> gshift;  // boards per wave
-  const int g = lane >> gshift;  // board slot inside the wave
-  const int j = lane & (G - 1);  // lane inside the board's group
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * BPW;
-  if (n0 >= a.N) return;  // wave-uniform
-  const int64_t N = a.N;
-  const int64_t n = n0 + g;
-  const bool live = n < N;
-  const int nb = (N - n0) < BPW ? (int)(N - n0) : BPW;
-  const int C = S * S, W = (C + 31) >> 5;
-  const int T = a.T, Tt = a.Tt;
-  const bool mc = a.mc != 0;
-  const uint32_t rowmask = S >= 32 ? 0xffffffffu : (1u << S) - 1;
-  const uint64_t gmask = (G == 64 ? ~0ull : ((1ull << G) - 1)) << (g << gshift);
-
-  unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;  // [BPW][3C] bytes, flat
-  unsigned char *stage = img + a.lds_stage_off;
-  Masks *L0 = reinterpret_cast<Masks *>(stage);
-  Masks *L = L0 + g;
-  cell_t *cells0 = reinterpret_cast<cell_t *>(stage + (size_t)BPW * sizeof(Masks));
-  cell_t *cells = cells0 + (size_t)g * (T + Tt);  // [T] tile cells, then [Tt] target cells
-  const cell_t *g_pos = reinterpret_cast<const cell_t *>(a.pos);
-  const cell_t *g_init = reinterpret_cast<const cell_t *>(a.init);
-  const cell_t *g_tgt = reinterpret_cast<const cell_t *>(a.tgt);
-
-  // ---- per-board scalars (the group's lanes load the same address: one request) ----
-  uint32_t action = 0, done_in = 0;
-  int32_t sc = 0;
-  if (live && a.op == OP_STEP) {
-    done_in = a.done[n];
-    sc = a.step_count[n];
-    action = a.actions[n];
-  }
-  int kind;  // 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells
-  uint32_t flags = 0;
-  if (a.op == OP_RESET) {
-    kind = 2;
-  } else if (a.op == OP_OBSERVE) {
-    kind = 1;
-  } else if (done_in) {
-    kind = a.autoreset ? 2 : 1;
-    flags = a.autoreset ? TS_FLAG_AUTORESET : TS_FLAG_STEPPED_DONE;
-  } else if (action > 3) {
-    kind = 1;
-    flags = TS_FLAG_BAD_ACTION;
-  } else {
-    kind = 0;
-  }
-  const int dir = (int)(action & 3u);
-  const bool vert = dir < 2, neg = (dir & 1) == 0;
-
-  // Which masks this launch needs (all wave-uniform except `vert`, which is per board):
-  //   column halves        : vertical slides, and the legality mask (all four directions)
-  //   post-move tiles Nr/Nc: set-equality win test (rows), legality mask (rows + columns)
-  //   targets          Tm  : set-equality win test
-  const bool need_new = !mc || a.valid != nullptr;
-  const bool need_cols = a.valid != nullptr || (kind == 0 && vert);
-
-  // ---- clear the line masks; park the packed obstacle words in the (not yet used) image ----
-  {
-    uint4 *z = reinterpret_cast<uint4 *>(L0);
-    const int n16 = BPW * (int)sizeof(Masks) / 16;
-    for (int i = lane; i < n16; i += kWave) z[i] = make_uint4(0, 0, 0, 0);
-  }
-  // (ts_is_won / ts_reward look at cells only: no obstacle masks needed)
-  const bool need_obstacles = a.op != OP_OBSERVE || a.obs || a.obs_u8 || a.onehot || a.valid;
-  uint32_t *words = reinterpret_cast<uint32_t *>(img) + g * kWords;
-  if (need_obstacles)
-    for (int w = j; w < kWords; w += G) words[w] = (live && w < W) ? a.blk[(int64_t)w * N + n] : 0u;
-  wave_sync();
-  for (int r = j; r < S && need_obstacles; r += G) {
-    const int bit0 = r * S, w0 = bit0 >> 5, sh = bit0 & 31;
-    uint64_t two = (uint64_t)words[w0];
-    if (w0 + 1 < kWords) two |= (uint64_t)words[w0 + 1] << 32;
-    const uint32_t rb = (uint32_t)(two >> sh) & rowmask;
-    L->Br[r] = rb;  // row r belongs to this lane alone
-    if (need_cols)
-      for (uint32_t m = rb; m; m &= m - 1) atomicOr(&L->Bc[ts::lsb(m)], 1u << r);
-  }
-
-  // ---- pass 1: pre-move cells into LDS, line occupancy by atomic OR ----
-  // Global loads go out kLoadBatch at a time before anything waits on them: a loop of
-  // load -> use -> load would pay one memory round trip per tile (measured: 303 us at 16
-  // tiles per lane vs 152 us at 2).
-  // The current cells are loaded before `done` (which decides between pos and init) has
-  // arrived; only boards being reset (rare in a step, all of them in ts_reset) load again.
-  const bool all_reset = a.op == OP_RESET;
-  // row t of an SoA array starts t * N bytes in: walk it with 64-bit pointer increments (one
-  // multiply per loop nest) instead of a 64-bit multiply per access
-  const int64_t lane_off = (int64_t)j * N + n;   // row j, this board
-  const int64_t group_stride = N << gshift;      // G rows further
-  for (int t0 = j; t0 < T; t0 += G * kLoadBatch) {
-    int v[kLoadBatch];
-    const int64_t off0 = lane_off + (int64_t)(t0 - j) * N;
-#pragma unroll
-    for (int u = 0; u < kLoadBatch; ++u) {
-      const int t = t0 + u * G;
-      v[u] = (live && t < T && !all_reset) ? (int)g_pos[off0 + u * group_stride] : 0;
-    }
-    if (kind == 2 && live) {
-#pragma unroll
-      for (int u = 0; u < kLoadBatch; ++u) {
-        const int t = t0 + u * G;
-        if (t < T) v[u] = (int)g_init[off0 + u * group_stride];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kLoadBatch; ++u) {
-      const int t = t0 + u * G;
-      if (t < T) {
-        const int pt = min(v[u], C - 1);
-        cells[t] = (cell_t)pt;
-        if (kind == 0) {  // occupancy of the lanes the move runs along
-          const int r = div_s(pt), c = pt - (int)__umul24((uint32_t)r, (uint32_t)S);
-          if (vert)
-            atomicOr(&L->O[c], 1u << r);
-          else
-            atomicOr(&L->O[r], 1u << c);
-        }
-      }
-    }
-  }
-  for (int t0 = j; t0 < Tt; t0 += G * kLoadBatch) {
-    int v[kLoadBatch];
-    const int64_t off0 = lane_off + (int64_t)(t0 - j) * N;
-#pragma unroll
-    for (int u = 0; u < kLoadBatch; ++u) {
-      const int t = t0 + u * G;
-      v[u] = (live && t < Tt) ? (int)g_tgt[off0 + u * group_stride] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < kLoadBatch; ++u) {
-      const int t = t0 + u * G;
-      if (t < Tt) {
-        const int tj = min(v[u], C - 1);
-        cells[T + t] = (cell_t)tj;
-        if (!mc) {
-          const int r = div_s(tj), c = tj - (int)__umul24((uint32_t)r, (uint32_t)S);
-          atomicOr(&L->Tm[r], 1u << c);
-        }
-      }
-    }
-  }
-  wave_sync();
-
-  // ---- pass 2: slide (state.py:120-170) ----
-  bool same = true, ordered = true;
-  cell_t *pos_out = reinterpret_cast<cell_t *>(a.pos) + lane_off;
-  for (int t = j; t < T; t += G, pos_out += group_stride) {
-    const int pt = cells[t];
-    int r = div_s(pt), c = pt - (int)__umul24((uint32_t)r, (uint32_t)S);
-    if (kind == 0) {
-      if (vert)
-        r = ts::slide_line(r, L->Bc[c], L->O[c], S, neg);
-      else
-        c = ts::slide_line(c, L->Br[r], L->O[r], S, neg);
-    }
-    const int qt = cell_of(r, c);
-    same &= qt == pt;
-    if (t < Tt) ordered &= qt == (int)cells[T + t];
-    if (need_new) {
-      atomicOr(&L->Nr[r], 1u << c);
-      if (a.valid) atomicOr(&L->Nc[c], 1u << r);
-    }
-    if (live && kind != 1) *pos_out = (cell_t)qt;
-    cells[t] = (cell_t)qt;  // only this lane reads cells[t] before the next wave_sync
-  }
-  wave_sync();
-  bool rows_equal = true;
-  if (!mc)
-    for (int r = j; r < S; r += G) rows_equal &= L->Nr[r] == L->Tm[r];
-  const bool all_same = (__ballot(same) & gmask) == gmask;
-  const bool all_ordered = (T == Tt) && ((__ballot(ordered) & gmask) == gmask);
-  const bool all_rows = (__ballot(rows_equal) & gmask) == gmask;
-
-  const bool won = mc ? all_ordered : all_rows;  // state.py:172-186
-  if (a.op == OP_OBSERVE && won) flags |= TS_FLAG_IS_WON;
-  if (kind == 0) {
-    if (won) flags |= TS_FLAG_IS_WON | TS_FLAG_SUCCESS;
-    if (all_same) flags |= TS_FLAG_INVALID_MOVE;
-    sc += 1;
-    uint32_t d = won ? 1u : 0u;
-    if (sc >= a.max_steps) {
-      d = 1u;
-      flags |= TS_FLAG_TIMEOUT;
-    }
-    if (live && j == 0) {
-      a.step_count[n] = sc;
-      a.done[n] = (uint8_t)d;
-    }
-  } else if (kind == 2 && live && j == 0) {
-    a.step_count[n] = 0;
-    a.done[n] = 0;
-  }
-  if (live && j == 0 && a.flags) a.flags[n] = (uint8_t)flags;
-
-  // ---- legality mask of the post-move board (environment.py:149-171) ----
-  if (a.valid) {
-    uint32_t vm = 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      bool moved = false;
-      for (int t = j; t < T; t += G) {
-        const int qt = cells[t];
-        const int r = div_s(qt), c = qt - (int)__umul24((uint32_t)r, (uint32_t)S);
-        const int x = d < 2 ? ts::slide_line(r, L->Bc[c], L->Nc[c], S, (d & 1) == 0)
-                            : ts::slide_line(c, L->Br[r], L->Nr[r], S, (d & 1) == 0);
-        moved |= x != (d < 2 ? r : c);
-      }
-      vm |= ((__ballot(moved) & gmask) != 0 ? 1u : 0u) << d;
-    }
-    if (live && j == 0) a.valid[n] = (uint8_t)vm;
-  }
-
-  // ---- build-defined Manhattan reward ----
-  if (a.reward) {
-    int sum = 0;
-    if (mc) {
-      const int m = T < Tt ? T : Tt;
-      for (int i = j; i < m; i += G) {
-        const int x = cells[i], y = cells[T + i];
-        {
-          const int xr = div_s(x), yr = div_s(y);
-          sum += abs(xr - yr) + abs((x - cell_of(xr, 0)) - (y - cell_of(yr, 0)));
-        }
-      }
-    } else if (Tt > 0) {
-      for (int i = j; i < T; i += G) {
-        const int x = cells[i];
-        int best = 1 << 30;
-        for (int k = 0; k < Tt; ++k) {
-          const int y = cells[T + k];
-          const int xr = div_s(x), yr = div_s(y);
-          const int dist = abs(xr - yr) + abs((x - cell_of(xr, 0)) - (y - cell_of(yr, 0)));
-          best = dist < best ? dist : best;
-        }
-        sum += best;
-      }
-    }
-    for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);  // stays inside the group: o < G
-    if (live && j == 0) a.reward[n] = -sum;
-  }
-
-  // ---- observation (state.py:188-211) through the LDS byte image ----
-  if (a.obs || a.obs_u8) {
-    wave_sync();  // the parked obstacle words are dead now
-    const int img_bytes = (BPW * 3 * C + 15) & ~15;
-    for (int off = lane * 16; off < img_bytes; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
-    wave_sync();
-    unsigned char *my = img + g * (3 * C);
-    if (live) {
-      for (int r = j; r < S; r += G)
-        for (uint32_t m = L->Br[r]; m; m &= m - 1) my[3 * cell_of(r, ts::lsb(m))] = 1;
-      for (int t = j; t < T; t += G) my[3 * cells[t] + 1] = (unsigned char)(mc ? t + 1 : 1);
-      for (int t = j; t < Tt; t += G) my[3 * cells[T + t] + 2] = (unsigned char)(mc ? t + 1 : 1);
-    }
-    wave_sync();
-    if (mc) {
-      // Duplicate target cells: the highest index must win (state.py:209-211), which lanes
-      // writing in parallel cannot promise.  Every lane reads its targets' bytes back; a byte
-      // that is not the lane's own index exposes a duplicate, and then one lane rewrites the
-      // board's target channel in index order.  (Levels from the factories never have any.)
-      bool clash = false;
-      if (live)
-        for (int t = j; t < Tt; t += G) clash |= my[3 * cells[T + t] + 2] != (unsigned char)(t + 1);
-      if ((__ballot(clash) & gmask) != 0) {
-        wave_sync();
-        if (live && j == 0)
-          for (int t = 0; t < Tt; ++t) my[3 * cells[T + t] + 2] = (unsigned char)(t + 1);
-      }
-      wave_sync();
-    }
-    if (a.obs) emit_bytes_as_f32(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.nt != 0);
-    if (a.obs_u8) emit_bytes_raw<4>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
-  }
-
-  // ---- build-defined one-hot planes: every output float evaluated from the staged cells ----
-  if (a.onehot) {
-    wave_sync();
-    const int Ch = a.onehot_ch;
-    const int D = Ch * C;
-    float *dst = a.onehot + n0 * (int64_t)D;
-    const int nfl = nb * D;
-    auto value = [&](int b, int r) -> float {
-      const int plane = r / C, cell = r - plane * C;
-      const int cr = div_s(cell), cc = cell - cell_of(cr, 0);
-      uint32_t bit;
-      if (plane == 0) {
-        bit = (L0[b].Br[cr] >> cc) & 1u;
-      } else if (mc) {
-        bit = (int)cells0[(size_t)b * (T + Tt) + plane - 1] == cell;  // tiles then targets, contiguous
-      } else {
-        bit = ((plane == 1 ? L0[b].Nr[cr] : L0[b].Tm[cr]) >> cc) & 1u;
-      }
-      return bit ? 1.0f : 0.0f;
-    };
-    int b = (4 * lane) / D, r = (4 * lane) - b * D;
-    const int nf4 = nfl >> 2;
-    for (int f4 = lane; f4 < nf4; f4 += kWave) {
-      float v[4];
-      int bb = b, rr = r;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v[k] = value(bb, rr);
-        if (++rr == D) {
-          rr = 0;
-          ++bb;
-        }
-      }
-      if (a.nt)
-        store_f4<true>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
-      else
-        store_f4<false>(reinterpret_cast<f32x4 *>(dst) + f4, f32x4{v[0], v[1], v[2], v[3]});
-      r += 4 * kWave;
-      while (r >= D) {
-        r -= D;
-        ++b;
-      }
-    }
-    const int tail = nfl & 3;
-    if (lane < tail) {
-      const int f = nf4 * 4 + lane;
-      dst[f] = value(f / D, f % D);
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// k_lines<WIDE, TPL>: the plain step / reset / encode path for S in 9..32 when the caller hands
-// in the level's precomputed line masks (ts_state.lines, built once per level by ts_prepare).
+// k_lines<WIDE, TPL, NT, EXTRAS>: S in 9..16 (WIDE = false, uint8 cell ids) and 17..32 (WIDE = true,
+// uint16 cell ids), every entry point.  Works from the level's precomputed line masks
+// (ts_state.lines, built once per level by ts_prepare — the reference builds its own per-level
+// table, move_to, in the GameState constructor: state.py:75-118).
 //
-// k_large re-derives everything that never changes during an episode on every step: it unpacks
-// the packed obstacle words row by row, transposes them into column masks with per-bit LDS
-// atomics, rebuilds the target row masks and reads the target bytes back to look for duplicate
-// target cells — 45.6 M vector instructions per cfg4 launch, 78 us of issue-bound work that did
-// not hide behind the 120 us of observation stores (profiles/r01_sq_counters.md).  Here those
-// tables are plain loads:
+// Round 1's large-board kernel re-derived everything that never changes during an episode on every
+// step: it unpacked the packed obstacle words row by row, transposed them into column masks with
+// per-bit LDS atomics, rebuilt the target row masks and read the target bytes back to look for
+// duplicate target cells — 45.6 M vector instructions per cfg4 launch, 78 us of issue-bound work
+// (profiles/r01_sq_counters.md).  Here those tables are plain loads (24.4 M, 40 us):
 //   * 16 lanes per board (4 boards per wave); lane j owns line j (and j + 16 above 16x16) and
 //     loads that line's obstacle masks  — one coalesced 4-B load per lane up to 16x16;
 //   * tiles live in registers (tile t -> lane t mod 16, TPL = tiles per lane is a template
 //     constant, so the tile loops are fully unrolled and their loads go out together);
 //   * per-step LDS work: one atomic OR per tile for the occupancy of the lines the move runs
 //     along, one read of the tile's own line; post-move row masks only for the set-equality win
-//     test of single-colour boards;
+//     test of single-colour boards and for the legality mask;
 //   * duplicate target cells are a property of the level: ts_prepare flags them, and only
-//     flagged boards pay for the "highest index wins" fix-up (state.py:209-211).
-// The legality mask, the reward and the one-hot planes stay with k_large (EXTRAS launches).
+//     flagged boards pay for the "highest index wins" fix-up (state.py:209-211);
+//   * EXTRAS: legality mask by free-neighbour tests, Manhattan reward, one-hot planes.
 // ------------------------------------------------------------------------------------------
 constexpr int kLinesG = 16;                   // lanes per board
 constexpr int kLinesBPW = kWave / kLinesG;    // boards per wave
@@ -1203,7 +830,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
     // packed run (the fixed point of the slide) the tile nearest the run's end touches an
     // obstacle / the wall and every other tile touches a tile; conversely a tile with a free
     // neighbour sits in a run that is not packed.  So four neighbour tests per tile replace four
-    // trial slides (k_large); tests/: every shape against the oracle's four trial moves.
+    // trial slides; tests/: every shape against the oracle's four trial moves.
     if (a.valid) {
       uint32_t mv = 0;
 #pragma unroll
@@ -1685,7 +1312,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   if ((a.op == OP_RESET || (a.op == OP_STEP && a.autoreset)) && T && !st->init) return TS_ERR_NULL;
   if (a.op != OP_OBSERVE && (!st->step_count || !st->done)) return TS_ERR_NULL;
   if (((uintptr_t)a.obs & 15u) || ((uintptr_t)a.onehot & 15u) || ((uintptr_t)a.obs_u8 & 15u)) return TS_ERR_ARG;  // 16-B stores
-  a.pos = static_cast<uint8_t *>(st->pos);  // k_large reinterprets these as uint16 above 16x16
+  a.pos = static_cast<uint8_t *>(st->pos);  // k_lines reinterprets these as uint16 above 16x16
   a.init = static_cast<const uint8_t *>(st->init);
   a.tgt = static_cast<const uint8_t *>(st->tgt);
   a.blk = st->blk;
@@ -1730,7 +1357,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
 #endif
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a);
-  } else if (st->lines && TS_USE_LINES) {
+  } else {
+    if (!st->lines) return TS_ERR_NULL;  // boards above 8x8 need the per-level tables of ts_prepare
     // step / reset / encode (+ legality mask, reward, one-hot) with the level's precomputed line masks: k_lines
     const bool wide = S > 16;
     a.lines = st->lines;
@@ -1771,35 +1399,6 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
       default: k = pick(std::integral_constant<int, 16>{}); break;
     }
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a, S, inv_s);
-  } else {
-    const bool wide = S > 16;
-    const uint32_t mask_bytes = wide ? (uint32_t)sizeof(LineMasks<32>) : (uint32_t)sizeof(LineMasks<16>);
-    const uint32_t cell_bytes = (uint32_t)((T + Tt) * (wide ? 2 : 1));
-    // Lanes per board, from a sweep of 13 shapes x {4, 8, 16} (profiles/r01_lanes_per_board_sweep.log):
-    // the fewest lanes (= most boards per wave, least fixed work per board) for which a wave
-    // still writes at most ~16 KiB of observation and no lane carries more than three tiles.
-    // Picks the measured best in every swept shape: 9x9/T4 -> 4, 9x9/T16, 10x10, 12x12 -> 8,
-    // 14x14 and larger (incl. 15x15/T32) -> 16.
-    int gshift = TS_LARGE_GSHIFT;
-    if (gshift < 0) {
-      gshift = 2;
-      while (gshift < 4 && ((uint32_t)(kWave >> gshift) * 12u * (uint32_t)C > 16u * 1024u || (T + (1 << gshift) - 1) >> gshift > 3)) ++gshift;
-    }
-    const int bpw = kWave >> gshift;
-    a.lds_stage_off = align16((uint32_t)(bpw * 3 * C));
-    a.lds_wave_bytes = a.lds_stage_off + align16((uint32_t)bpw * (mask_bytes + cell_bytes));
-    int waves = TS_WAVES_PER_BLOCK > 4 ? 4 : TS_WAVES_PER_BLOCK;
-    while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
-    if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
-    if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
-    const int64_t boards_per_block = (int64_t)waves * bpw;
-    const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
-    if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-    const uint32_t inv_s = (uint32_t)((65536 + S - 1) / S);
-    if (wide)
-      hipLaunchKernelGGL(k_large<true>, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, gshift, inv_s);
-    else
-      hipLaunchKernelGGL(k_large<false>, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a, S, gshift, inv_s);
   }
   return finish_launch();
 }

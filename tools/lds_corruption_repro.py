@@ -4,8 +4,9 @@
 Round 2 found that the LDS size was never the cause (profiles/r02_lds_corruption_bisect.log,
 profiles/r02_lds_probe.log).  What fails is one COMPILED FORM of k_small<8, 0, false>: the current
 source with the single-pass observation block of commit 0690d71 pasted back, at -O2 / -O3
-(-O1 of the same text is clean).  This script rebuilds exactly that form from the current
-source, so the defect can be re-examined after a compiler update:
+(-O1 of the same text is clean).  This script rebuilds that form from the current source
+(it reproduced the failure when k_small still took the store policy as a run-time flag, commit 06962e4; later
+source changes move the register allocation, so a clean run today does not mean the defect is gone):
 
     python tools/lds_corruption_repro.py build      # here: writes build/variants/cur_oldobs*.so
     TS_SHOW_DIFF=1 python tools/check_variants_vs_oracle.py 8,20,10 524288 cur_oldobs,cur_oldobs_O1,base   # GPU box
@@ -36,7 +37,7 @@ OLD_OBS_BLOCK = '''  if (a.obs) {
       }
     }
     wave_sync();
-    emit_bytes_as_f32(img, a.obs + n0 * (3 * C), nb * 3 * C, lane, a.nt != 0);
+    emit_bytes_as_f32<NT>(img, a.obs + n0 * (3 * C), nb * 3 * C, lane);
   }
 
 '''
