@@ -330,7 +330,6 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   } else {
     kind = 0;
   }
-  const uint8_t *src = kind == 2 ? a.init : a.pos;
   const int dir = (int)(action & 3u);
 
   // ---- pass 1: pre-move cells and occupancy ----
@@ -350,11 +349,19 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
     // Loads go out kSmallBatch at a time, UNCONDITIONALLY: lanes past the batch read the last
     // board, rows past the tile count read the last row (results unused).  With a predicate per
     // load the compiler emitted a branch and an `s_waitcnt vmcnt(0)` after every single load —
-    // eight dependent memory round trips per batch instead of one.
+    // eight dependent memory round trips per batch instead of one.  The cells come from `pos` (or
+    // `init` in ts_reset) without waiting for `done`; boards that autoreset inside a step (rare)
+    // read their row of `init` again.
+    const uint8_t *cur = all_reset ? a.init : a.pos;
+    const bool reload = kind == 2 && !all_reset;
     for (int t0 = 0; t0 < T; t0 += kSmallBatch) {
       int v[kSmallBatch];
 #pragma unroll
-      for (int u = 0; u < kSmallBatch; ++u) v[u] = (int)src[(int64_t)min(t0 + u, T - 1) * N + nl];
+      for (int u = 0; u < kSmallBatch; ++u) v[u] = (int)cur[(int64_t)min(t0 + u, T - 1) * N + nl];
+      if (reload) {
+#pragma unroll
+        for (int u = 0; u < kSmallBatch; ++u) v[u] = (int)a.init[(int64_t)min(t0 + u, T - 1) * N + nl];
+      }
 #pragma unroll
       for (int u = 0; u < kSmallBatch; ++u) {
         if (t0 + u < T) {
