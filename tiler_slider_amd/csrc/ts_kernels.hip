@@ -68,6 +68,9 @@
 #ifndef TS_LINES_WAVES  // waves per block of k_lines
 #define TS_LINES_WAVES 4
 #endif
+#ifndef TS_SMALL_OOC_BPW  // boards per wave of k_small for out-of-cache launches: 0 = the measured policy, else forced
+#define TS_SMALL_OOC_BPW 0
+#endif
 #ifndef TS_SMALL_LDS_PAD  // diagnostic: extra dynamic LDS per wave of k_small
 #define TS_SMALL_LDS_PAD 0
 #endif
@@ -120,6 +123,7 @@ struct KArgs {
   uint32_t nt;  // nontemporal observation stores
   uint32_t oh_boards;   // one-hot byte image: boards per chunk (0 = evaluate per float)
   uint32_t lds_oh_off;  // offset of that image inside the wave's carve
+  uint32_t bpw;         // k_small: boards per wave (64, or fewer beyond the Infinity Cache)
 };
 
 // Orders LDS traffic between the lanes of ONE wave.  The hardware executes a wave's DS
@@ -271,12 +275,15 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * kWave;
+  // a.bpw boards per wave: 64 (one per lane), or fewer for launches beyond the Infinity Cache (the
+  // upper lanes idle; a wave's contiguous chunk of output shrinks accordingly)
+  const int bpw = (int)a.bpw;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform; no block-level barrier exists in this kernel
   const int64_t N = a.N;
   const int64_t n = n0 + lane;
-  const bool live = n < N;
-  const int nb = (N - n0) < kWave ? (int)(N - n0) : kWave;
+  const bool live = n < N && lane < bpw;
+  const int nb = (N - n0) < bpw ? (int)(N - n0) : bpw;
   const int T = TFIX > 0 ? TFIX : a.T;
   const int Tt = TFIX > 0 ? TFIX : a.Tt;
   const bool mc = a.mc != 0;
@@ -1292,12 +1299,25 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
     if (chunk >= 40u * 1024u) return {1, 4};
     return {1, chunk < 5u * 1024u ? 12 : chunk < 8u * 1024u ? 10 : 7};
   }
-  // k_small (all of a wave's loads in flight at once): about 64 KiB of output owned by resident waves per CU
-  if (chunk >= 40u * 1024u) return {1, 3};                 // cfg2 (51 KB): 3 -> 135 us, 4 -> 138, unbounded 145
-  if (chunk >= 16u * 1024u) return {1, 4};                 // 5x5 .. 7x7: 4 wins by 5-6 %
-  if (chunk >= 8u * 1024u) return {1, tiles <= 2 ? 5 : 6};  // 4x4: 4M boards 5 -> 121 us, 10 -> 137, unbounded 142
-  if (chunk >= 4u * 1024u) return {1, 10};                 // 3x3
-  return {1, 16};                                          // 2x2, 1x1
+  // k_small, half waves (32 boards per wave, see small_boards_per_wave): `chunk` is the half wave's output
+  if (chunk >= 22u * 1024u) return {1, 5};                     // cfg2 (25.6 KB): 5 -> 121 us, 4 -> 135, 6..24 -> 126
+  if (chunk >= 16u * 1024u) return {1, 8};                     // 7x7: flat from 6 up
+  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 7 : 10};    // 5x5, 6x6: 7 (10 with more tiles: more loads to hide)
+  if (chunk >= 4u * 1024u) return {1, tiles <= 2 ? 12 : 14};   // 4x4: 4M boards 12 -> 113 us, 10 -> 122, 16 -> 119
+  return {1, 16};  // 2x2, 1x1 (full waves; 3x3's 6.9 KB land in the branch above)
+}
+
+// Boards per wave of k_small.  Beyond the Infinity Cache the register-path kernels run HALF waves —
+// 32 boards, the upper lanes idle — once a full wave would write 8 KB or more: the transition
+// arithmetic is a small part of such a launch (7.6 of 33 us at cfg1), while halving every wave's
+// chunk of output at the same bytes in flight per CU is worth 3-12 % (4x4 at 4M boards 126 -> 113 us,
+// cfg2 132 -> 121, 6x6 77 -> 68; profiles/r02_ooc_residency_sweep.log).
+int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t chunk_full_wave) {
+#if TS_SMALL_OOC_BPW > 0
+  return (out_of_cache && register_path) ? TS_SMALL_OOC_BPW : kWave;
+#else
+  return (out_of_cache && register_path && chunk_full_wave >= 8u * 1024u && TS_OOC_WAVES != 0) ? 32 : kWave;
+#endif
 }
 
 int32_t finish_launch() {
@@ -1348,13 +1368,14 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);
-    const Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)kWave * out_per_board, T);
+    a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board);
+    const Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
     if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
     if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
     const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
-    const int64_t boards_per_block = (int64_t)waves * kWave;
+    const int64_t boards_per_block = (int64_t)waves * a.bpw;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
     const bool extras = a.valid || a.reward || a.onehot;
