@@ -68,6 +68,9 @@
 #ifndef TS_LINES_WAVES  // waves per block of k_lines
 #define TS_LINES_WAVES 4
 #endif
+#ifndef TS_LINES_OOC_BPW  // experiment: boards per wave of k_lines for out-of-cache launches (0 = 4)
+#define TS_LINES_OOC_BPW 0
+#endif
 #ifndef TS_SMALL_OOC_BPW  // boards per wave of k_small for out-of-cache launches: 0 = the measured policy, else forced
 #define TS_SMALL_OOC_BPW 0
 #endif
@@ -123,7 +126,7 @@ struct KArgs {
   uint32_t nt;  // nontemporal observation stores
   uint32_t oh_boards;   // one-hot byte image: boards per chunk (0 = evaluate per float)
   uint32_t lds_oh_off;  // offset of that image inside the wave's carve
-  uint32_t bpw;         // k_small: boards per wave (64, or fewer beyond the Infinity Cache)
+  uint32_t bpw;         // boards per wave (k_small: 64, k_lines: 4; fewer beyond the Infinity Cache)
 };
 
 // Orders LDS traffic between the lanes of ONE wave.  The hardware executes a wave's DS
@@ -669,15 +672,16 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int g = lane >> 4, j = lane & (G - 1);
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * BPW;
+  const int bpw = (int)a.bpw;  // boards per wave: 4, or 2 (the upper lanes idle) — see lines_boards_per_wave
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform
   const int64_t N = a.N;
   const int64_t n = n0 + g;
-  const bool live = n < N;
+  const bool live = n < N && g < bpw;
   const int64_t nl = live ? n : N - 1;  // lanes past the batch read the last board and write nothing:
                                         // every load below is unconditional, so all of them are in
                                         // flight before the first one is waited for
-  const int nb = (N - n0) < BPW ? (int)(N - n0) : BPW;
+  const int nb = (N - n0) < bpw ? (int)(N - n0) : bpw;
   const int C = S * S;
   const int T = a.T, Tt = a.Tt;
   const bool mc = a.mc != 0;
@@ -1398,14 +1402,15 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_oh_off = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) +
                    (a.reward && !d->multi_color ? align16((uint32_t)(kLinesBPW * Tt * 2)) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
+    a.bpw = (a.nt && TS_LINES_OOC_BPW > 0) ? TS_LINES_OOC_BPW : kLinesBPW;
     const Residency res = ooc_residency(a.nt != 0, true, false,
-                                        (uint64_t)kLinesBPW * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull)), T);
+                                        (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull)), T);
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
     if (const size_t lim = device_block_lds_limit(); lim && (size_t)waves * a.lds_wave_bytes > lim) return TS_ERR_LIMIT;
     const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
-    const int64_t boards_per_block = (int64_t)waves * kLinesBPW;
+    const int64_t boards_per_block = (int64_t)waves * a.bpw;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
     const uint32_t inv_s = (uint32_t)((65536 + S - 1) / S);
