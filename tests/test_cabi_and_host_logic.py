@@ -212,6 +212,17 @@ def test_bench_byte_accounting_matches_survey():
     assert bench.host_cpu_share() >= 1
 
 
+def test_bench_gpus_n_without_launcher_fails_cleanly_without_gpus(capsys):
+    """`python bench.py --gpus N` starts its own ranks; on a box with fewer GPUs it must say so and
+    return 2 (no hang, no traceback) — here: zero GPUs."""
+    import bench
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    assert bench.spawn_ranks(2) == 2
+    assert "needs 2 GPUs" in capsys.readouterr().err
+
+
 def test_level_records_keep_the_reference_names():
     """The level record under the reference's name (tests/test_user_scenarios.py:22-31 builds levels as
     ImageLoader.ImageProcessed); the image parser and its constants are out of scope."""

@@ -203,20 +203,28 @@ def test_generator_and_actions_match_twin(torch_cuda, oracle):
             assert all(((int(blk[p >> 5, n]) >> (p & 31)) & 1) == 0 for p in col)
 
 
-@pytest.mark.parametrize("S,T,K,N", [(4, 2, 2, 1 << 20), (5, 2, 3, 1 << 20), (15, 32, 24, 1 << 18)])
+@pytest.mark.parametrize("S,T,K,N", [(4, 2, 2, 1 << 20), (5, 2, 3, 1 << 20), (15, 32, 24, 1 << 18), (4, 2, 2, 1 << 22),
+                                     (6, 3, 4, 1 << 20)])
 def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N):
-    """BASELINE.json configs 1, 2 and 4 at full size: a complete oracle replay of every board for a
-    few steps (the C oracle is fast enough), then properties that do not need the oracle:
-    sliding twice in one direction is idempotent, tile / obstacle counts are conserved in the
-    observation, and autoreset keeps every board live."""
+    """BASELINE.json configs 1, 2 and 4 at full size, the 4M-board sibling of config 1 and a 6x6
+    batch beyond the Infinity Cache (two-pass image in half waves): a complete oracle replay of every
+    board for a few steps (the C oracle is fast enough) — with the optional outputs and, on a
+    second environment, without them, so that the out-of-cache launch policies of the plain kernels
+    (one-wave blocks, bounded residency, half waves) are exercised at the sizes where they apply —
+    then properties that do not need the oracle: sliding twice in one direction is idempotent,
+    tile / obstacle counts are conserved in the observation, and autoreset keeps every board live."""
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv
     env = VecTilerSliderEnv.random(N, size=S, num_tiles=T, num_obstacles=K, seed=0x715311DE, multi_color=True,
                                    max_steps=2**30, auto_reset=True, with_reward=True)
+    plain = VecTilerSliderEnv.from_arrays(S, env._blk, env._init, env._tgt, multi_color=True, max_steps=2**30, auto_reset=True)
     blk = env._blk.cpu().numpy().view(np.uint32)
     ref = oracle.OracleBatch(S, True, 2**30, blk, env._init.cpu().numpy(), env._tgt.cpu().numpy())
-    np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset())
-    steps = 6 if S <= 5 else 3
+    want0 = ref.reset()
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
+    np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
+    del want0
+    steps = 6 if S <= 5 and N <= 1 << 20 else 3
     for step in range(steps):
         act = oracle.fill_actions(N, seed=0xAC710005, step_index=step)
         obs, done, info = env.step(torch.from_numpy(act))
@@ -225,6 +233,11 @@ def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N):
         assert np.array_equal(info["flags"].cpu().numpy(), want["flags"])
         assert np.array_equal(info["reward"].cpu().numpy(), want["reward"])
         assert np.array_equal(obs.cpu().numpy(), want["obs"])
+        pobs, pdone, pinfo = plain.step(torch.from_numpy(act))
+        assert np.array_equal(plain.positions.cpu().numpy(), ref.pos)
+        assert np.array_equal(pinfo["flags"].cpu().numpy(), want["flags"])
+        assert np.array_equal(pobs.cpu().numpy(), want["obs"])
+    del plain
     # idempotence: a board that was just slid LEFT does not change when slid LEFT again
     act = torch.full((N,), 2, dtype=torch.uint8, device=env.device)
     _, _, info1 = env.step(act)
