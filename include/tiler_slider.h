@@ -140,8 +140,9 @@ int32_t ts_check_dims(const ts_dims *dims);
 /* reset(): pos <- init, step_count <- 0, done <- 0, obs <- encode(init) (obs may be NULL).
  * ref: explainrl/environment/environment.py:82-98 (TilerSliderEnv.reset),
  *      explainrl/environment/state.py:47-73 (GameState.__init__).  The reference's
- *      move_to table (state.py:75-118) is not materialised: slide destinations are
- *      recomputed from the obstacle bitmask inside ts_step. */
+ *      move_to table (state.py:75-118) is not materialised: up to 8x8 slide destinations are
+ *      recomputed from the obstacle bitboard, above that from the per-level line masks of
+ *      ts_prepare (below). */
 int32_t ts_reset(const ts_dims *dims, const ts_state *st, float *obs, void *stream);
 
 /* step(): slide-and-pack every tile of every board in its action's direction, then
@@ -177,7 +178,8 @@ int32_t ts_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8, v
 int32_t ts_expand_u8(const uint8_t *src, float *dst, int64_t count, void *stream);
 
 /* Build-defined extensions (absent from the reference, environment.py:5 says reward is
- * "handled separately"; parity unpinned vs the reference, pinned by oracle/):
+ * "handled separately"; no reference output exists to compare with — kernels and oracle are
+ * pinned to NumPy expressions over the reference's recorded cells, tests/test_gpu_parity.py):
  *   one-hot: plane 0 obstacles; multi_color: plane 1+i tile i, plane 1+T+j target j;
  *            single colour: plane 1 any tile, plane 2 any target.
  *            It is a function of the STATE (obstacles, tile cells, target cells), and of the
@@ -214,8 +216,7 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
  * away const); board n uses the counter-based stream (seed, board_offset + n), so
  * shards of one global batch can be generated independently on each GPU.
  * ref: explainrl/environment/environment.py:202-234 (create_simple_env) for the
- *      distribution only — the reference's MT19937 stream is reproduced on the host
- *      (tiler_slider_amd.factory), not here. */
+ *      distribution only — the reference's own seed -> level map is ts_generate_mt19937. */
 int32_t ts_generate(const ts_dims *dims, const ts_state *st, uint64_t seed, int64_t board_offset,
                     int32_t n_obstacles, void *stream);
 
