@@ -57,6 +57,22 @@ def algorithmic_bytes_per_board_step(size, tiles, onehot, reward, multi_color=Tr
     return read + write
 
 
+def dominant_kernel(cfg, n, L):
+    """Name of the kernel ts_step launches for this config (the policy of ts_kernels.hip: launch())."""
+    S, T = cfg["size"], cfg["tiles"]
+    if S > 8:
+        return "k_lines"
+    out_bytes = (12 * S * S + (4 * S * S * (1 + 2 * T) if cfg["onehot"] else 0)) * n
+    two_per_lane = (2 <= S <= 5 and 1 <= T <= 8 and not cfg["onehot"] and n % 2 == 0 and out_bytes <= 256 << 20
+                    and n >= L.ts_tuning(_cabi_key_multi_min_boards(), -1))
+    return "k_multi" if two_per_lane else "k_small"
+
+
+def _cabi_key_multi_min_boards():
+    from tiler_slider_amd import _cabi
+    return _cabi.TUNE_MULTI_MIN_BOARDS
+
+
 def pmc_traffic(config, boards):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/traffic_pmc.json; counters cannot be read from inside this process).  None when no
@@ -332,7 +348,7 @@ def main():
                          # `frac` is from HIP events on the launch stream
                          "frac_wall": achieved_wall / HBM_PEAK_GBS,
                          "frac_of_copy_ceiling": achieved / COPY_CEILING_GBS, "copy_ceiling": COPY_CEILING_GBS,
-                         "kernel": "k_small" if cfg["size"] <= 8 else "k_lines",
+                         "kernel": dominant_kernel(cfg, n, L),
                          "kernel_us": kern_s * 1e6, "algorithmic_bytes_per_board_step": bps,
                          "algorithmic_bytes_per_launch": bps * n,
                          # a launch that moves less than the 256 MiB Infinity Cache runs at the on-die

@@ -208,6 +208,20 @@ int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void
 int32_t ts_lines_words(int32_t size);
 int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, void *stream);
 
+/* --- launch policy ------------------------------------------------------------ */
+
+/* Process-wide launch-policy knobs.  They choose between kernels that produce identical
+ * results (every policy is under the same parity tests), so they affect speed only.
+ *   TS_TUNE_MULTI_MIN_BOARDS  batch size from which cache-resident launches of boards up to
+ *       5x5 with n_tiles == n_targets <= 8 run two boards per lane (k_multi: half the narrow
+ *       state accesses and half the waves of the one-board-per-lane kernel; needs an even
+ *       n_boards and 2-element-aligned rows, else the one-board kernel runs).  Default
+ *       524288 (measured break-even on MI355X); 0 = whenever applicable; INT64_MAX = never.
+ * value >= 0 sets the knob, value < 0 only queries.  Returns the value before the call, or
+ * -1 for an unknown key.  Thread-safe (one atomic per knob). */
+#define TS_TUNE_MULTI_MIN_BOARDS 0
+int64_t ts_tuning(int32_t key, int64_t value);
+
 /* --- synthetic inputs (bench / tests) --------------------------------------- */
 
 /* Random level per board with the distribution of the reference's level factory:

@@ -34,6 +34,19 @@ def test_library_exports_every_declared_symbol():
     assert L.ts_status_string(0) == b"ok" and b"NULL" in L.ts_status_string(-1)
 
 
+def test_launch_policy_knob():
+    """ts_tuning: query, set, restore; unknown keys are refused (no GPU involved)."""
+    from tiler_slider_amd import _cabi
+    L = _cabi.lib()
+    default = L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, -1)
+    assert default == 524288
+    assert L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, 0) == default
+    assert L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, -1) == 0
+    assert L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, default) == 0
+    assert L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, -5) == default
+    assert L.ts_tuning(99, 1) == -1 and L.ts_tuning(-1, -1) == -1
+
+
 def test_argument_validation_precedes_any_launch():
     from tiler_slider_amd import _cabi
     L = _cabi.lib()

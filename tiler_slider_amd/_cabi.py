@@ -20,11 +20,12 @@ OK, ERR_NULL, ERR_DIMS, ERR_LIMIT, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0x08
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
 MODE_STRICT, MODE_AUTORESET = 0, 1
+TUNE_MULTI_MIN_BOARDS = 0
 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
            "ts_encode_u8", "ts_expand_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions",
-           "ts_lines_words", "ts_prepare", "ts_generate_mt19937")
+           "ts_lines_words", "ts_prepare", "ts_generate_mt19937", "ts_tuning")
 
 
 class Dims(C.Structure):
@@ -104,6 +105,8 @@ def lib():
     L.ts_cell_bytes.restype = C.c_int32
     L.ts_lines_words.argtypes = [C.c_int32]
     L.ts_lines_words.restype = C.c_int32
+    L.ts_tuning.argtypes = [C.c_int32, C.c_int64]
+    L.ts_tuning.restype = C.c_int64
     L.ts_onehot_channels.argtypes = [DP]
     L.ts_onehot_channels.restype = C.c_int32
     L.ts_check_dims.argtypes = [DP]

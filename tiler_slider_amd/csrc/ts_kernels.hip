@@ -24,6 +24,8 @@
 // No MFMA: nothing here is a contraction.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "../../include/tiler_slider.h"
 #include "ts_core.h"
 
@@ -47,7 +49,10 @@
 #ifndef TS_EMIT_PRIO  // s_setprio level while a wave streams its observation out (0 = unchanged)
 #define TS_EMIT_PRIO 0
 #endif
-#ifndef TS_ABLATE  // development only (tools/variant_bench.py): 1 = skip the observation stores
+#ifndef TS_ABLATE_LOADS
+#define TS_ABLATE_LOADS 0
+#endif
+#ifndef TS_ABLATE  // development only (tools/variant_bench.py): 1 = skip the observation stores, 2 = k_small: only those
 #define TS_ABLATE 0
 #endif
 #ifndef TS_MAX_TFIX  // largest tile count with a register-resident instantiation of k_small (4, 6 or 8)
@@ -58,6 +63,12 @@
 #endif
 #ifndef TS_XCD_PIECE  // 0 = each XCD owns one contiguous eighth of the batch; P > 0 = pieces of P blocks, round-robin
 #define TS_XCD_PIECE 0
+#endif
+#ifndef TS_MULTI_G  // boards per lane of k_multi (2 or 4); 0 = never launch it
+#define TS_MULTI_G 2
+#endif
+#ifndef TS_MULTI_MIN_BOARDS  // below this many boards k_small's four times as many waves fill the chip better
+#define TS_MULTI_MIN_BOARDS 524288
 #endif
 #ifndef TS_WAVES_PER_BLOCK
 #define TS_WAVES_PER_BLOCK 4
@@ -292,6 +303,27 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   const bool mc = a.mc != 0;
 
   unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;
+#if TS_ABLATE == 2  // development only: the observation stores alone (no state loads, no transition)
+  if (a.obs) {
+    for (int c0 = 0; c0 < nb; c0 += kObsBoards) {
+      if (c0) wave_sync();
+      for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, lane & 1, 0);
+#if TS_ABLATE_LOADS
+      {  // + the state loads of a plain step, consumed by one LDS byte
+        const int64_t nl = (n0 + lane) < a.N ? n0 + lane : a.N - 1;
+        uint32_t x = a.blk[nl] ^ a.done[nl] ^ (uint32_t)a.step_count[nl] ^ a.actions[nl];
+        for (int t = 0; t < TR; ++t) x ^= a.pos[(int64_t)t * a.N + nl] ^ a.tgt[(int64_t)t * a.N + nl];
+        wave_sync();
+        img[lane * 3 * C] = (unsigned char)(x & 1);
+      }
+#endif
+      wave_sync();
+      const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
+      emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
+    }
+    return;
+  }
+#endif
   unsigned char *stage = img + a.lds_stage_off;
   M *st_blk = reinterpret_cast<M *>(stage);  // [64] obstacles
   M *st_occ = st_blk + kWave;                // [64] post-move tile mask
@@ -394,7 +426,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       ordered &= q[t] == tg[t];
       occ2 |= M(1) << q[t];
       tgm |= M(1) << tg[t];
-      if (live && kind != 1) a.pos[(int64_t)t * N + n] = (uint8_t)q[t];
+      if (live && kind != 1 && TS_ABLATE != 3) a.pos[(int64_t)t * N + n] = (uint8_t)q[t];
     }
   } else {
     for (int t = 0; t < T; ++t) {
@@ -447,15 +479,15 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       d = 1u;
       flags |= TS_FLAG_TIMEOUT;
     }
-    if (live) {
+    if (live && TS_ABLATE != 3) {
       a.step_count[n] = sc;
       a.done[n] = (uint8_t)d;
     }
-  } else if (kind == 2 && live) {
+  } else if (kind == 2 && live && TS_ABLATE != 3) {
     a.step_count[n] = 0;
     a.done[n] = 0;
   }
-  if (live && a.flags) a.flags[n] = (uint8_t)flags;
+  if (live && a.flags && (TS_ABLATE != 3 || flags == 0xEE)) a.flags[n] = (uint8_t)flags;
 
   // ---- legality mask of the post-move board (environment.py:149-171) ----
   if (EXTRAS && a.valid) {
@@ -626,6 +658,209 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       const int f = nf4 * 4 + lane;
       dst[f] = value(f / D, f % D);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_multi<S, TFIX, EXTRAS, G>: S <= 5, cache-resident launches: G boards per lane (round 2).
+//
+// At cfg1 the observation stores alone take 27.2 us, the whole step 33.2: the nine narrow state
+// loads and five narrow state stores of every 64-board wave cost 1.9 + 1.75 us although they move
+// a twentieth of the bytes (profiles/r02_cfg1_small_ops.log) — requests, not bytes.  Here a lane
+// owns G CONSECUTIVE boards, so every state row is read and written G boards per lane at a time
+// (one 32-bit access for four cell bytes, one 128-bit access for four obstacle words / counters):
+// a quarter of the memory instructions and of the waves for the same boards.  The transition itself
+// is k_small's register path run G times per lane.  Needs n_boards % G == 0 and G-element-aligned
+// buffers (checked on the host, which otherwise launches k_small); no one-hot (k_small has it).
+// Out-of-cache launches stay with k_small: there the bytes a wave writes in one piece decide
+// (ooc_residency), and G boards per lane multiply them.
+// ------------------------------------------------------------------------------------------
+template <int G> struct MultiPack;
+template <> struct MultiPack<2> { using bytes_t = uint16_t; using words_t = uint2; };
+template <> struct MultiPack<4> { using bytes_t = uint32_t; using words_t = uint4; };
+__device__ __forceinline__ uint32_t word_of(const uint2 &v, int g) { return g == 0 ? v.x : v.y; }
+__device__ __forceinline__ uint32_t word_of(const uint4 &v, int g) { return g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w; }
+__device__ __forceinline__ void set_word(uint2 &v, int g, uint32_t x) { (g == 0 ? v.x : v.y) = x; }
+__device__ __forceinline__ void set_word(uint4 &v, int g, uint32_t x) { (g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w) = x; }
+
+template <int S, int TFIX, bool EXTRAS, int G>
+__global__ __launch_bounds__(256) void k_multi(const KArgs a) {
+  using BB = ts::Bitboard<S>;
+  using M = typename BB::mask_t;
+  static_assert(sizeof(M) == 4 && TFIX >= 1, "k_multi: boards up to 5x5, cells in registers");
+  using P = typename MultiPack<G>::bytes_t;  // G bytes: one per board of the lane
+  using V = typename MultiPack<G>::words_t;  // G 32-bit words
+  constexpr int C = BB::C;
+  constexpr int kBoards = kWave * G;
+  constexpr int kImg = kBoards * 3 * C;  // multiple of 16
+  constexpr M kFull = (M(1) << C) - 1;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int64_t N = a.N;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * kBoards;
+  if (n0 >= N) return;  // wave-uniform; no block-level barrier exists in this kernel
+  const int64_t n = n0 + (int64_t)lane * G;  // first board of the lane; N % G == 0, so a lane is live or dead as a whole
+  const bool live = n < N;
+  const int64_t nl = live ? n : N - G;  // dead lanes read the last group and write nothing
+  const int nb = (N - n0) < kBoards ? (int)(N - n0) : kBoards;
+  const bool mc = a.mc != 0;
+  unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;
+
+  // ---- loads: unconditional, all issued before the first is consumed ----
+  const bool all_reset = a.op == OP_RESET;  // uniform
+  const uint8_t *cur = all_reset ? a.init : a.pos;
+  const V blkv = *reinterpret_cast<const V *>(a.blk + nl);
+  P pw[TFIX], tw[TFIX];
+#pragma unroll
+  for (int t = 0; t < TFIX; ++t) {
+    pw[t] = *reinterpret_cast<const P *>(cur + (int64_t)t * N + nl);
+    tw[t] = *reinterpret_cast<const P *>(a.tgt + (int64_t)t * N + nl);
+  }
+  P actw = 0, donew = 0;
+  V scv = {};
+  if (a.op == OP_STEP) {  // uniform
+    donew = *reinterpret_cast<const P *>(a.done + nl);
+    scv = *reinterpret_cast<const V *>(a.step_count + nl);
+    actw = *reinterpret_cast<const P *>(a.actions + nl);
+  }
+  if (a.obs || a.obs_u8) {  // uniform
+    for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
+    wave_sync();
+  }
+  P iw[TFIX];
+#pragma unroll
+  for (int t = 0; t < TFIX; ++t) iw[t] = pw[t];
+  if (a.op == OP_STEP && a.autoreset && donew != 0) {  // some board of this lane restarts inside the step (rare)
+#pragma unroll
+    for (int t = 0; t < TFIX; ++t) iw[t] = *reinterpret_cast<const P *>(a.init + (int64_t)t * N + nl);
+  }
+
+  P out_pos[TFIX], out_done = 0, out_flags = 0, out_valid = 0;
+#pragma unroll
+  for (int t = 0; t < TFIX; ++t) out_pos[t] = 0;
+  V out_sc = {}, out_rw = {};
+
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int sh = 8 * g;
+    const M blk = (M)word_of(blkv, g) & kFull;  // bits past the board would index outside the LDS image
+    const uint32_t done_in = (uint32_t)(donew >> sh) & 255u, action = (uint32_t)(actw >> sh) & 255u;
+    int32_t sc = (int32_t)word_of(scv, g);
+    // kind: 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells (as k_small)
+    int kind;
+    uint32_t flags = 0;
+    if (a.op == OP_RESET) {
+      kind = 2;
+    } else if (a.op == OP_OBSERVE) {
+      kind = 1;
+    } else if (done_in) {  // environment.py:113-114
+      kind = a.autoreset ? 2 : 1;
+      flags = a.autoreset ? TS_FLAG_AUTORESET : TS_FLAG_STEPPED_DONE;
+    } else if (action > 3) {  // environment.py:116-117
+      kind = 1;
+      flags = TS_FLAG_BAD_ACTION;
+    } else {
+      kind = 0;
+    }
+    const int dir = (int)(action & 3u);
+    int p[TFIX], q[TFIX], tg[TFIX];
+    M occ = 0;
+#pragma unroll
+    for (int t = 0; t < TFIX; ++t) {
+      const int raw = (int)((kind == 2 ? iw[t] : pw[t]) >> sh) & 255;
+      p[t] = min(raw, C - 1);  // clamp: malformed ids stay in-board
+      tg[t] = min((int)(tw[t] >> sh) & 255, C - 1);
+      occ |= M(1) << p[t];
+    }
+    M occ2 = 0, tgm = 0;
+    bool same = true, ordered = true;
+#pragma unroll
+    for (int t = 0; t < TFIX; ++t) {
+      q[t] = kind == 0 ? ts::slide_cell<S>(p[t], occ, blk, dir) : p[t];
+      same &= q[t] == p[t];
+      ordered &= q[t] == tg[t];
+      occ2 |= M(1) << q[t];
+      tgm |= M(1) << tg[t];
+      // an untouched board keeps its byte exactly as it was loaded
+      out_pos[t] |= (P)((P)(kind == 1 ? (int)(pw[t] >> sh) & 255 : q[t]) << sh);
+    }
+    const bool won = mc ? ordered : (occ2 == tgm);  // state.py:172-186
+    if (a.op == OP_OBSERVE && won) flags |= TS_FLAG_IS_WON;
+    uint32_t d = done_in;
+    if (kind == 0) {
+      if (won) flags |= TS_FLAG_IS_WON | TS_FLAG_SUCCESS;
+      if (same) flags |= TS_FLAG_INVALID_MOVE;
+      sc += 1;
+      d = won ? 1u : 0u;
+      if (sc >= a.max_steps) {
+        d = 1u;
+        flags |= TS_FLAG_TIMEOUT;
+      }
+    } else if (kind == 2) {
+      sc = 0;
+      d = 0;
+    }
+    set_word(out_sc, g, (uint32_t)sc);
+    out_done |= (P)((P)d << sh);
+    out_flags |= (P)((P)flags << sh);
+
+    if (EXTRAS && a.valid) {  // legality mask of the post-move board (environment.py:149-171)
+      uint32_t vm = 0;
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {
+        bool moved = false;
+#pragma unroll
+        for (int t = 0; t < TFIX; ++t) moved |= ts::slide_cell<S>(q[t], occ2, blk, dd) != q[t];
+        vm |= (moved ? 1u : 0u) << dd;
+      }
+      out_valid |= (P)((P)vm << sh);
+    }
+    if (EXTRAS && a.reward) {  // build-defined Manhattan reward
+      int sum = 0;
+      if (mc) {
+#pragma unroll
+        for (int i = 0; i < TFIX; ++i) sum += abs(q[i] / S - tg[i] / S) + abs(q[i] % S - tg[i] % S);
+      } else {
+#pragma unroll
+        for (int i = 0; i < TFIX; ++i) {
+          int best = 1 << 30;
+#pragma unroll
+          for (int j = 0; j < TFIX; ++j) {
+            const int dist = abs(q[i] / S - tg[j] / S) + abs(q[i] % S - tg[j] % S);
+            best = dist < best ? dist : best;
+          }
+          sum += best;
+        }
+      }
+      set_word(out_rw, g, (uint32_t)(-sum));
+    }
+    if (live && (a.obs || a.obs_u8)) {  // observation bytes of this board (state.py:188-211)
+      unsigned char *my = img + (lane * G + g) * (3 * C);
+      for (M m = blk; m; m &= m - 1) my[3 * ts::lsb(m)] = 1;
+#pragma unroll
+      for (int t = 0; t < TFIX; ++t) my[3 * q[t] + 1] = (unsigned char)(mc ? t + 1 : 1);
+#pragma unroll
+      for (int t = 0; t < TFIX; ++t) my[3 * tg[t] + 2] = (unsigned char)(mc ? t + 1 : 1);
+    }
+  }
+
+  if (live) {
+    if (a.op != OP_OBSERVE) {
+#pragma unroll
+      for (int t = 0; t < TFIX; ++t) *reinterpret_cast<P *>(a.pos + (int64_t)t * N + n) = out_pos[t];
+      *reinterpret_cast<V *>(a.step_count + n) = out_sc;
+      *reinterpret_cast<P *>(a.done + n) = out_done;
+    }
+    if (a.flags) *reinterpret_cast<P *>(a.flags + n) = out_flags;
+    if (EXTRAS && a.valid) *reinterpret_cast<P *>(a.valid + n) = out_valid;
+    if (EXTRAS && a.reward) *reinterpret_cast<V *>(a.reward + n) = out_rw;
+  }
+  if (a.obs || a.obs_u8) {
+    wave_sync();
+    if (a.obs) emit_bytes_as_f32<false>(img, a.obs + n0 * (3 * C), nb * 3 * C, lane);
+    if (a.obs_u8) emit_bytes_raw<16>(img, a.obs_u8 + n0 * (3 * C), nb * 3 * C, lane);
   }
 }
 
@@ -1184,6 +1419,7 @@ __global__ __launch_bounds__(256) void k_fill_actions(uint8_t *actions, int64_t 
 // Host side of the C-ABI
 // ------------------------------------------------------------------------------------------
 thread_local int32_t t_last_hip_error = 0;
+std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_TUNE_MULTI_MIN_BOARDS)
 
 int32_t check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
@@ -1232,6 +1468,49 @@ SmallKernel small_kernel(int S, int tfix) {
     default: return small_kernel_for<0, EXTRAS, NT>(S);
   }
 }
+
+#if TS_MULTI_G > 0
+template <int TFIX, bool EXTRAS>
+SmallKernel multi_kernel_for(int S) {
+  switch (S) {
+    case 2: return k_multi<2, TFIX, EXTRAS, TS_MULTI_G>;
+    case 3: return k_multi<3, TFIX, EXTRAS, TS_MULTI_G>;
+    case 4: return k_multi<4, TFIX, EXTRAS, TS_MULTI_G>;
+    case 5: return k_multi<5, TFIX, EXTRAS, TS_MULTI_G>;
+    default: return nullptr;
+  }
+}
+
+template <bool EXTRAS>
+SmallKernel multi_kernel(int S, int tfix) {
+  switch (tfix) {
+    case 1: return multi_kernel_for<1, EXTRAS>(S);
+    case 2: return multi_kernel_for<2, EXTRAS>(S);
+    case 3: return multi_kernel_for<3, EXTRAS>(S);
+    case 4: return multi_kernel_for<4, EXTRAS>(S);
+#if TS_MAX_TFIX >= 6
+    case 5: return multi_kernel_for<5, EXTRAS>(S);
+    case 6: return multi_kernel_for<6, EXTRAS>(S);
+#endif
+#if TS_MAX_TFIX >= 8
+    case 7: return multi_kernel_for<7, EXTRAS>(S);
+    case 8: return multi_kernel_for<8, EXTRAS>(S);
+#endif
+    default: return nullptr;
+  }
+}
+
+// k_multi reads and writes G boards per lane with one access: the batch must be a multiple of G and every
+// state / output row G-element aligned (rows of a [T][N] array start at t * N)
+bool multi_applicable(const KArgs &a) {
+  constexpr uintptr_t G = TS_MULTI_G;
+  if (a.N % (int64_t)G != 0 || a.N < g_multi_min_boards.load(std::memory_order_relaxed) || a.nt || a.onehot) return false;
+  const uintptr_t bytes = (uintptr_t)a.pos | (uintptr_t)a.init | (uintptr_t)a.tgt | (uintptr_t)a.done | (uintptr_t)a.actions |
+                          (uintptr_t)a.flags | (uintptr_t)a.valid;
+  const uintptr_t words = (uintptr_t)a.blk | (uintptr_t)a.step_count | (uintptr_t)a.reward;
+  return (bytes & (G - 1)) == 0 && (words & (4 * G - 1)) == 0;
+}
+#endif
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
@@ -1367,6 +1646,20 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
       for (uint32_t nbc = kWave; nbc >= 4 && !a.oh_boards; nbc >>= 1)
         if (align16(nbc * (uint32_t)(a.onehot_ch * C)) <= 16u * 1024u) a.oh_boards = nbc;
     }
+#if TS_MULTI_G > 0
+    if (S >= 2 && S <= 5 && tfix > 0 && multi_applicable(a)) {  // cache-resident: G boards per lane
+      const bool extras = a.valid || a.reward;
+      SmallKernel k = extras ? multi_kernel<true>(S, tfix) : multi_kernel<false>(S, tfix);
+      a.lds_wave_bytes = (a.obs || a.obs_u8) ? align16((uint32_t)(kWave * TS_MULTI_G * 3 * C)) : 0u;
+      a.bpw = kWave * TS_MULTI_G;
+      int waves = TS_WAVES_PER_BLOCK;
+      while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
+      const int64_t boards_per_block = (int64_t)waves * a.bpw;
+      const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
+      hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a);
+      return finish_launch();
+    }
+#endif
     const bool need_stage = tfix == 0 || (a.onehot && !a.oh_boards);
     a.lds_stage_off = align16((uint32_t)(small_obs_boards(C) * 3 * C));
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
@@ -1591,6 +1884,11 @@ int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void
   a.op = OP_OBSERVE;
   a.reward = reward;
   return launch(dims, st, a, stream);
+}
+
+int64_t ts_tuning(int32_t key, int64_t value) {
+  if (key != TS_TUNE_MULTI_MIN_BOARDS) return -1;
+  return value >= 0 ? g_multi_min_boards.exchange(value) : g_multi_min_boards.load();
 }
 
 int32_t ts_lines_words(int32_t size) { return size < 9 || size > TS_MAX_SIZE ? 0 : lines_record_words(size > 16); }
