@@ -721,3 +721,32 @@ def test_stepinfo_snapshot_and_double_buffered_observations(torch_cuda, oracle):
     np.testing.assert_array_equal(info0["flags"].cpu().numpy(), want1["flags"])  # the live view has moved on (documented)
     with pytest.raises(ValueError):
         env.capture_steps([a0.to(env.device)])
+
+
+def test_placement_trials_leave_no_trace(torch_cuda, oracle):
+    """placement_trials times the real step kernel on candidate output buffers at construction; afterwards the
+    environment must be indistinguishable from one built without it (state restored, outputs zeroed)."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    small = VecTilerSliderEnv.random(1000, size=4, num_tiles=2, num_obstacles=2, seed=3, placement_trials=4)
+    assert "skipped" in small.placement_report
+    N = 1 << 20  # 5x5: 315 MB of observation per step, beyond the Infinity Cache
+    kw = dict(size=5, num_tiles=2, num_obstacles=3, seed=11, multi_color=True, max_steps=7, with_reward=True)
+    for autoreset in (False, True):
+        plain = VecTilerSliderEnv.random(N, auto_reset=autoreset, **kw)
+        tuned = VecTilerSliderEnv.random(N, auto_reset=autoreset, placement_trials=3, obs_buffers=2, **kw)
+        rep = tuned.placement_report
+        assert 1 <= rep["trials"] <= 3 and len(rep["us_per_step"]) == rep["trials"] and 0 <= rep["chosen"] < rep["trials"]
+        assert rep["us_per_step"][rep["chosen"]] == min(rep["us_per_step"])
+        for t in ("_pos", "_step_count", "_done", "_flags", "_reward"):
+            assert torch.equal(getattr(plain, t), getattr(tuned, t)), t
+        assert int(tuned._obs.abs().sum()) == 0
+        assert torch.equal(plain.reset(), tuned.reset())
+        for step in range(9):
+            act = torch.from_numpy(oracle.fill_actions(N, seed=8, step_index=step))
+            o1, d1, i1 = plain.step(act)
+            o2, d2, i2 = tuned.step(act)
+            assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(i1["flags"], i2["flags"])
+            assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(plain.positions, tuned.positions)
+        del plain, tuned
+        torch.cuda.empty_cache()

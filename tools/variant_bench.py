@@ -68,6 +68,24 @@ def run(a):
         t = torch.empty(n, dtype=torch.uint8, device=dev)
         _cabi.check(_cabi.lib().ts_fill_actions(n, bench.ACTION_SEED, 0, i, t.data_ptr(), stream), "fill")
         ring.append(t)
+    if a.pick:  # --pick slowest|fastest: rate every allocation with the shipped library first, then A/B on that one
+        rated = []
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for k, e in enumerate(keep):
+            e.reset()
+            for i in range(10):
+                e.step_async(ring[i & 15])
+            ev0.record()
+            for i in range(100):
+                e.step_async(ring[i & 15])
+            ev1.record()
+            torch.cuda.synchronize()
+            rated.append((ev0.elapsed_time(ev1) * 10, k))
+        print("allocations (us per step, shipped library):", " ".join(f"{k}:{us:.1f}" for us, k in rated))
+        us, k = min(rated) if a.pick == "fastest" else max(rated)
+        env = keep[k]
+        print(f"using allocation {k} ({a.pick}, {us:.1f} us)")
+        env.reset()
     libs = {}
     for name in names:
         L = C.CDLL(os.path.join(VDIR, f"{name}.so"))
@@ -137,5 +155,6 @@ if __name__ == "__main__":
     r.add_argument("--no-check", action="store_true")
     r.add_argument("--tag", default="")
     r.add_argument("--placement", type=int, default=0, help="use the K-th allocation of the environment")
+    r.add_argument("--pick", choices=["slowest", "fastest"], help="with --placement K: rate the K+1 allocations, use that one")
     args = ap.parse_args()
     build(args.specs) if args.cmd == "build" else run(args)
