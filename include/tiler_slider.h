@@ -96,7 +96,11 @@ typedef struct ts_dims {
   int32_t n_targets;   /* Tt, 0..TS_MAX_TILES        (len(target_locations)) */
   int32_t multi_color; /* 0 / 1                      (GameState.multi_color) */
   int32_t max_steps;   /* >= 1                       (TilerSliderEnv.max_steps) */
-  int32_t reserved;    /* must be 0 */
+  int32_t launch_hint; /* 0 = the library's launch policy.  -3 .. +3: resident blocks per CU of launches whose
+                        * outputs do not fit the Infinity Cache, relative to that policy - speed only, never
+                        * results; the best value depends on where the output buffers were allocated
+                        * (VecTilerSliderEnv(placement_trials=k) finds it).
+                        * Anything else: TS_ERR_DIMS.  (The field was `reserved`, must-be-zero, before.) */
 } ts_dims;
 
 typedef struct ts_state {

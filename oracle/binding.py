@@ -19,7 +19,7 @@ MODE_STRICT, MODE_AUTORESET = 0, 1
 
 class Dims(C.Structure):
     _fields_ = [("n_boards", C.c_int64), ("size", C.c_int32), ("n_tiles", C.c_int32), ("n_targets", C.c_int32),
-                ("multi_color", C.c_int32), ("max_steps", C.c_int32), ("reserved", C.c_int32)]
+                ("multi_color", C.c_int32), ("max_steps", C.c_int32), ("launch_hint", C.c_int32)]
 
 
 class State(C.Structure):

@@ -186,7 +186,7 @@ void tso_state_array(int32_t S, const uint8_t *blocked, int32_t T, const int32_t
  * ---------------------------------------------------------------------------------- */
 static int check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
-  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->reserved != 0 ||
+  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -3 || d->launch_hint > 3 ||
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;
   if (d->size > TS_MAX_SIZE || d->n_tiles > TS_MAX_TILES || d->n_targets > TS_MAX_TILES) return TS_ERR_LIMIT;

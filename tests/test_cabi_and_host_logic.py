@@ -57,7 +57,11 @@ def test_argument_validation_precedes_any_launch():
     for bad, want in ((_cabi.Dims(-1, 4, 2, 2, 0, 100, 0), _cabi.ERR_DIMS), (_cabi.Dims(8, 0, 2, 2, 0, 100, 0), _cabi.ERR_DIMS),
                       (_cabi.Dims(8, 33, 2, 2, 0, 100, 0), _cabi.ERR_LIMIT), (_cabi.Dims(8, 4, 17, 2, 0, 100, 0), _cabi.ERR_DIMS),
                       (_cabi.Dims(8, 32, 256, 2, 0, 100, 0), _cabi.ERR_LIMIT), (_cabi.Dims(8, 4, 2, 2, 2, 100, 0), _cabi.ERR_DIMS),
-                      (_cabi.Dims(8, 4, 2, 2, 0, 0, 0), _cabi.ERR_DIMS), (_cabi.Dims(8, 4, 2, 2, 0, 100, 1), _cabi.ERR_DIMS)):
+                      (_cabi.Dims(8, 4, 2, 2, 0, 0, 0), _cabi.ERR_DIMS), (_cabi.Dims(8, 4, 2, 2, 0, 100, 4), _cabi.ERR_DIMS), (_cabi.Dims(8, 4, 2, 2, 0, 100, -4), _cabi.ERR_DIMS)):
+        assert L.ts_check_dims(C.byref(bad)) == want
+    for hint in (-3, -1, 1, 3):  # launch_hint: speed only
+        assert L.ts_check_dims(C.byref(_cabi.Dims(8, 4, 2, 2, 0, 100, hint))) == _cabi.OK
+    for bad, want in ():
         assert L.ts_check_dims(C.byref(bad)) == want
     st, out = _cabi.State(), _cabi.StepOut()
     assert L.ts_step(C.byref(ok), C.byref(st), None, 0, C.byref(out), None) == _cabi.ERR_NULL

@@ -738,6 +738,7 @@ def test_placement_trials_leave_no_trace(torch_cuda, oracle):
         rep = tuned.placement_report
         assert 1 <= rep["trials"] <= 3 and len(rep["us_per_step"]) == rep["trials"] and 0 <= rep["chosen"] < rep["trials"]
         assert rep["us_per_step"][rep["chosen"]] == min(rep["us_per_step"])
+        assert tuned._dims.launch_hint == rep["launch_hint"][rep["chosen"]] and -1 <= tuned._dims.launch_hint <= 1
         for t in ("_pos", "_step_count", "_done", "_flags", "_reward"):
             assert torch.equal(getattr(plain, t), getattr(tuned, t)), t
         assert int(tuned._obs.abs().sum()) == 0
@@ -750,3 +751,28 @@ def test_placement_trials_leave_no_trace(torch_cuda, oracle):
             assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(plain.positions, tuned.positions)
         del plain, tuned
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("S,T,K,N,onehot", [(5, 2, 3, 1 << 20, True), (15, 32, 24, 1 << 18, False), (4, 2, 2, 1 << 22, False)])
+def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, onehot):
+    """ts_dims.launch_hint moves the resident blocks per CU of launches beyond the Infinity Cache (k_small half
+    waves, k_small + one-hot, k_lines): every value must give the buffers the library's own policy gives."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv
+    kw = dict(size=S, num_tiles=T, num_obstacles=K, seed=5, multi_color=True, max_steps=6, auto_reset=True,
+              with_reward=True, with_onehot=onehot)
+    ref = VecTilerSliderEnv.random(N, **kw)
+    env = VecTilerSliderEnv.random(N, **kw)
+    ref.reset(), env.reset()
+    for step, hint in enumerate((-3, -2, -1, 1, 2, 3)):
+        act = torch.from_numpy(oracle.fill_actions(N, seed=21, step_index=step))
+        env._dims.launch_hint = hint
+        o1, d1, i1 = ref.step(act)
+        o2, d2, i2 = env.step(act)
+        assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(i1["flags"], i2["flags"]), hint
+        assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(ref.positions, env.positions), hint
+        if onehot:
+            assert torch.equal(i1["onehot"], i2["onehot"]), hint
+    env._dims.launch_hint = 4
+    with pytest.raises(Exception):
+        env.step(act)

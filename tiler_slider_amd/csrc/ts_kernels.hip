@@ -1423,7 +1423,7 @@ std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_T
 
 int32_t check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
-  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->reserved != 0 ||
+  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -3 || d->launch_hint > 3 ||
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;
   if (d->size > TS_MAX_SIZE || d->n_tiles > TS_MAX_TILES || d->n_targets > TS_MAX_TILES) return TS_ERR_LIMIT;
@@ -1603,6 +1603,13 @@ int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t chunk_
 #endif
 }
 
+// ts_dims.launch_hint: resident blocks per CU relative to the policy, only where the policy bounds them at all
+void apply_launch_hint(Residency &res, int32_t hint) {
+  if (hint == 0 || res.blocks_per_cu <= 0) return;
+  const int b = res.blocks_per_cu + hint;
+  res.blocks_per_cu = b < 1 ? 1 : b;
+}
+
 int32_t finish_launch() {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) {
@@ -1666,7 +1673,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board);
-    const Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
+    Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
+    apply_launch_hint(res, d->launch_hint);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
     if (a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
@@ -1696,8 +1704,9 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                    (a.reward && !d->multi_color ? align16((uint32_t)(kLinesBPW * Tt * 2)) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
     a.bpw = (a.nt && TS_LINES_OOC_BPW > 0) ? TS_LINES_OOC_BPW : kLinesBPW;
-    const Residency res = ooc_residency(a.nt != 0, true, false,
+    Residency res = ooc_residency(a.nt != 0, true, false,
                                         (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull)), T);
+    apply_launch_hint(res, d->launch_hint);
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*

@@ -96,7 +96,8 @@ class VecTilerSliderEnv:
                       the allocation (profiles/r02_placement_study.log).  With k > 1 the
                       constructor allocates up to k candidate sets of those buffers, times a few steps of the
                       real kernel on each (the state is restored afterwards) and keeps the fastest; the others
-                      are released.  Costs k times the output memory during construction and a few
+                      are released.  Per candidate it also rates one resident block per CU less and more than
+                      the library's policy (`ts_dims.launch_hint`) and keeps the best of the three.  Costs k times the output memory during construction and a few
                       milliseconds; no effect on results.  Default 1 (off).  `placement_report` holds the timings.
         host_mapped : keep every buffer in pinned host memory that the GPU reads and writes in
                       place (zero-copy).  For a handful of boards driven move by move from Python
@@ -295,7 +296,19 @@ class VecTilerSliderEnv:
         acts = self._empty(N, torch.uint8)
         self._call("ts_fill_actions", N, C.c_uint64(0xAC710005), 0, 0, _ptr(acts))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        candidates, times = [(self._obs_ring, self._onehot)], []
+        candidates, times, hints = [(self._obs_ring, self._onehot)], [], []
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+
+        def rate(out):
+            for i in range(3):
+                _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(out), stream), "ts_step")
+            ev0.record()
+            for i in range(8):
+                _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(out), stream), "ts_step")
+            ev1.record()
+            ev1.synchronize()
+            return ev0.elapsed_time(ev1) * 1e3 / 8
+
         with torch.cuda.device(self.device):
             for k in range(trials):
                 if k:
@@ -303,19 +316,16 @@ class VecTilerSliderEnv:
                                        torch.zeros_like(self._onehot) if self._onehot is not None else None))
                 self._obs_ring, self._onehot = candidates[k]
                 self._bind_outputs()
-                per_ring = []
-                for out in self._outs:  # every buffer of the ring is rated; the set counts as its slowest member
-                    for i in range(3):
-                        _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET,
-                                              C.byref(out), torch.cuda.current_stream(self.device).cuda_stream), "ts_step")
-                    ev0.record()
-                    for i in range(8):
-                        _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET,
-                                              C.byref(out), torch.cuda.current_stream(self.device).cuda_stream), "ts_step")
-                    ev1.record()
-                    ev1.synchronize()
-                    per_ring.append(ev0.elapsed_time(ev1) * 1e3 / 8)
-                times.append(max(per_ring))
+                # How many waves a CU should keep resident depends on the allocation too (cfg2: five on a fast one,
+                # four on a slow one: 146 -> 135 us): rate the library's policy and one block per CU less / more
+                # (ts_dims.launch_hint).  Every buffer of the ring is rated; a set counts as its slowest member.
+                per_hint = {}
+                for hint in (0, -1, 1):
+                    self._dims.launch_hint = hint
+                    per_hint[hint] = max(rate(out) for out in self._outs)
+                hint = min(per_hint, key=per_hint.__getitem__)
+                times.append(per_hint[hint])
+                hints.append(hint)
                 # two clearly separated speeds seen and the current one is of the fast kind: stop looking
                 if len(times) >= 2 and times[-1] <= min(times) * 1.02 and max(times) >= min(times) * 1.06:
                     break
@@ -331,7 +341,9 @@ class VecTilerSliderEnv:
             if t is not None:
                 t.zero_()
         self._bind_outputs()
-        self.placement_report = {"us_per_step": [round(t, 2) for t in times], "chosen": best, "trials": len(times)}
+        self._dims.launch_hint = hints[best]
+        self.placement_report = {"us_per_step": [round(t, 2) for t in times], "launch_hint": hints, "chosen": best,
+                                 "trials": len(times)}
 
     # buffers live on the GPU, or (host_mapped) in pinned host memory the GPU addresses directly
     def _pin(self, t):
