@@ -1583,7 +1583,10 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
     return {1, chunk < 5u * 1024u ? 12 : chunk < 8u * 1024u ? 10 : 7};
   }
   // k_small, half waves (32 boards per wave, see small_boards_per_wave): `chunk` is the half wave's output
-  if (chunk >= 22u * 1024u) return {1, 5};                     // cfg2 (25.6 KB): 5 -> 121 us, 4 -> 135, 6..24 -> 126
+  // cfg2 (25.6 KB): on a fast allocation 5 -> 122 us, 4 -> 133, 6 -> 125; on a slow one 5 -> 146, 4 -> 135, 6 -> 148
+  // (profiles/r02_placement_study.log).  Five is a gamble (3 of 8 allocations fast), four the same on both; a caller
+  // that rates its buffers (VecTilerSliderEnv placement_trials) moves up with ts_dims.launch_hint = +1.
+  if (chunk >= 22u * 1024u) return {1, 4};
   if (chunk >= 16u * 1024u) return {1, 8};                     // 7x7: flat from 6 up
   if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 7 : 10};    // 5x5, 6x6: 7 (10 with more tiles: more loads to hide)
   if (chunk >= 4u * 1024u) return {1, tiles <= 2 ? 12 : 14};   // 4x4: 4M boards 12 -> 113 us, 10 -> 122, 16 -> 119
