@@ -719,8 +719,22 @@ def test_stepinfo_snapshot_and_double_buffered_observations(torch_cuda, oracle):
     np.testing.assert_array_equal(snap["flags"].cpu().numpy(), want0["flags"])
     np.testing.assert_array_equal(snap["reward"].cpu().numpy(), want0["reward"])
     np.testing.assert_array_equal(info0["flags"].cpu().numpy(), want1["flags"])  # the live view has moved on (documented)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError):  # an odd number of steps would leave the ring on the other buffer
         env.capture_steps([a0.to(env.device)])
+    # a captured sequence cycles through the ring like eager steps: replay twice, compare with the oracle
+    acts = [torch.from_numpy(oracle.fill_actions(N, seed=2, step_index=i)).to(env.device) for i in range(4)]
+    graph = env.capture_steps(acts)
+    for rep in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        for k, a in enumerate(acts):
+            want = ref.step(a.cpu().numpy(), reward=True)
+            if k == len(acts) - 2:
+                want_prev = want
+        np.testing.assert_array_equal(env._obs.cpu().numpy(), want["obs"])  # the last written buffer
+        other = env._obs_ring[1 - env._obs_slot]
+        np.testing.assert_array_equal(other.cpu().numpy(), want_prev["obs"])  # the step before it, intact
+        np.testing.assert_array_equal(env.positions.cpu().numpy(), ref.pos)
 
 
 def test_placement_trials_leave_no_trace(torch_cuda, oracle):

@@ -413,13 +413,16 @@ class VecTilerSliderEnv:
         into a hipGraph and return it; `graph.replay()` then runs the whole sequence with one
         host call.  For small batches, where a step is shorter than a kernel launch from Python
         (4096 4x4 boards: ~5 us of kernel per ~8 us of launch), this removes the host from the
-        loop; large batches are not launch-bound and gain nothing."""
+        loop; large batches are not launch-bound and gain nothing.  With obs_buffers = k the captured steps
+        cycle through the k observation buffers like eager steps (pass a multiple of k action buffers)."""
         self._require_open()
         if self.host_mapped:
             raise ValueError("capture_steps needs device buffers (host_mapped=False)")
-        if len(self._obs_ring) > 1:
-            raise ValueError("capture_steps needs obs_buffers=1 (a replayed graph cannot rotate buffers)")
         bufs = [b for b in action_buffers]
+        if len(bufs) % len(self._obs_ring):
+            # the captured sequence rotates through the observation ring exactly as eager steps do; it must end on
+            # the slot it started from, so that `_obs` names the last written buffer after every replay
+            raise ValueError(f"capture_steps needs a multiple of obs_buffers={len(self._obs_ring)} action buffers")
         for b in bufs:
             if not (isinstance(b, torch.Tensor) and b.dtype == torch.uint8 and b.device == self.device
                     and b.shape == (self.num_envs,) and b.is_contiguous()):
