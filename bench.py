@@ -157,7 +157,11 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+_STDOUT_FD = None
+
+
 def main():
+    global _STDOUT_FD
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
@@ -184,6 +188,10 @@ def main():
         # touched the GPU (torch.cuda.device_count() does not initialise it on ROCm); the ranks
         # are fresh children, this process only relays their output and exit code.
         raise SystemExit(spawn_ranks(args.gpus))
+
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)  # restored for the one JSON line; until then fd 1 is stderr
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -378,6 +386,10 @@ def main():
             line["allgather"] = gather
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
+        # libraries write to the process's stdout on their own (RCCL prints a version banner when the first
+        # communicator is created): everything up to here went to stderr, the JSON line alone goes to stdout
+        sys.stdout.flush()
+        os.dup2(_STDOUT_FD, 1)
         print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()
