@@ -15,8 +15,11 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every
  *    call is asynchronous on that stream; none synchronises the device.
  *  - Return value: TS_OK (0) or a negative ts_status.  No C++ exception crosses
- *    this boundary.  The library keeps no global mutable state; calls are
- *    re-entrant.
+ *    this boundary.  The library keeps no global mutable state other than the
+ *    launch-policy knobs of ts_tuning (atomics, speed only); calls are re-entrant.
+ *  - A board that a step leaves untouched (done on entry in strict mode, action
+ *    byte > 3) keeps every state byte; a kernel may store those bytes back
+ *    unchanged, so state rows must not be written by anyone else during a call.
  *
  * Device data layout (struct-of-arrays, board index fastest; N = n_boards,
  * S = size, C = S*S, cell id p = r*S + c with row 0 at the top):
