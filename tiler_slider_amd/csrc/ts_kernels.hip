@@ -49,6 +49,9 @@
 #ifndef TS_EMIT_PRIO  // s_setprio level while a wave streams its observation out (0 = unchanged)
 #define TS_EMIT_PRIO 0
 #endif
+#ifndef TS_ABLATE_DENSE  // store-only ablation writes observation-like data (1 byte in 8 non-zero) instead of near-zeros
+#define TS_ABLATE_DENSE 0
+#endif
 #ifndef TS_ABLATE_LOADS
 #define TS_ABLATE_LOADS 0
 #endif
@@ -307,7 +310,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   if (a.obs) {
     for (int c0 = 0; c0 < nb; c0 += kObsBoards) {
       if (c0) wave_sync();
-      for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, lane & 1, 0);
+      for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = TS_ABLATE_DENSE ? make_uint4(1, 0, 0x0200, 0) : make_uint4(0, 0, lane & 1, 0);
 #if TS_ABLATE_LOADS
       {  // + the state loads of a plain step, consumed by one LDS byte
         const int64_t nl = (n0 + lane) < a.N ? n0 + lane : a.N - 1;
