@@ -247,7 +247,8 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 #define TS_SMALL_BOUNDS __launch_bounds__(TS_SMALL_THREADS)
 #endif
 
-// Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only).  This
+// Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only; tools/xcc_probe.py read
+// HW_REG_XCC_ID == blockIdx % 8 for every block of every launch shape used here, profiles/r02_xcc_probe.log).  This
 // bijective remap gives the blocks that share an XCD one contiguous range of boards instead of
 // every 8th block:
 //   * output beyond the Infinity Cache: a fill kernel whose waves own 12 KiB chunks writes 708 MB
