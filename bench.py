@@ -174,6 +174,7 @@ def main():
     ap.add_argument("--placement-trials", type=int, default=6,
                     help="VecTilerSliderEnv(placement_trials=...): candidate allocations of the output buffers rated at "
                          "construction for batches beyond the Infinity Cache (1 = take the first; reported in config)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-halves-on-two-streams figure")
     ap.add_argument("--no-sibling", action="store_true", help="skip the out-of-cache sibling of a cache-resident config")
     ap.add_argument("--compact-u8", action="store_true",
                     help="also time the opt-in uint8-observation variant (reported as compact_u8_obs; off by "
@@ -332,6 +333,45 @@ def main():
         del big, acts
         torch.cuda.empty_cache()
 
+    # two halves of the batch on two streams (tiler_slider_amd.pipelined): what a double-buffered actor loop gets when
+    # one half steps while it works on the other - the ramps of consecutive launches overlap.  Not the headline: the
+    # synchronous step() of the reference API joins all boards every step.
+    pipelined = None
+    if world == 1 and not args.no_pipelined and n % 2 == 0:
+        from tiler_slider_amd import PipelinedTilerSliderEnv
+        pe = PipelinedTilerSliderEnv(n, parts=2, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
+                                     seed=LEVEL_SEED, multi_color=True, max_steps=2**30, device=device, auto_reset=True,
+                                     with_reward=cfg["reward"], with_onehot=cfg["onehot"], placement_trials=args.placement_trials)
+        pe.reset()
+        pe.wait()
+        half = n // 2
+        pacts = [[ring[i][p * half:(p + 1) * half].contiguous() for i in range(4)] for p in range(2)]
+        k = min(args.steps, 200)
+        # the action buffers exist already: launch straight on the parts' streams (no per-step join with this stream)
+        def run(steps):
+            for i in range(steps):
+                for p in range(2):
+                    pe.step_part_async(p, pacts[p][i & 3], actions_ready=True)
+        run(10)
+        pe.wait()
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for s_ in pe.streams:
+            s_.wait_event(e0)
+        t0 = time.perf_counter()
+        run(k)
+        pe.wait()
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / k
+        pipelined = {"parts": 2, "value": n / us * 1e6, "unit": "env-steps/s", "us_per_step_of_all_boards": us,
+                     "us_per_step_wall": (time.perf_counter() - t0) * 1e6 / k, "steps": k,
+                     "note": "two halves on two streams, no join between steps (tiler_slider_amd.pipelined)"}
+        pe.close()
+        del pe, pacts
+        torch.cuda.empty_cache()
+
     gather = None
     if multi and not args.no_gather:
         gather = time_gathers(env, ring, world, n, dist, torch, device, min(args.steps, 20))
@@ -380,6 +420,8 @@ def main():
             line["roofline"]["hbm_sibling"] = sibling
         if api is not None:
             line["python_step_api"] = api
+        if pipelined is not None:
+            line["pipelined_halves"] = pipelined
         if compact is not None:
             line["compact_u8_obs"] = compact
         if gather is not None:

@@ -790,3 +790,38 @@ def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, o
     env._dims.launch_hint = 4
     with pytest.raises(Exception):
         env.step(act)
+
+
+def test_pipelined_parts_equal_one_environment(torch_cuda, oracle):
+    """PipelinedTilerSliderEnv: two / three parts on their own streams give, slice by slice, what one environment
+    over all boards gives (levels are a function of (seed, global board index))."""
+    torch = torch_cuda
+    from tiler_slider_amd import PipelinedTilerSliderEnv, VecTilerSliderEnv
+    N = 6 * 20011
+    kw = dict(size=4, num_tiles=2, num_obstacles=2, seed=99, multi_color=True, max_steps=9, auto_reset=True, with_reward=True)
+    one = VecTilerSliderEnv.random(N, **kw)
+    want0 = one.reset().clone()
+    acts = [torch.from_numpy(oracle.fill_actions(N, seed=4, step_index=i)).cuda() for i in range(7)]
+    for parts in (2, 3):
+        env = PipelinedTilerSliderEnv(N, parts=parts, **kw)
+        per = N // parts
+        obs = env.reset()
+        env.wait()
+        torch.cuda.synchronize()
+        for p in range(parts):
+            assert torch.equal(obs[p], want0[p * per:(p + 1) * per])
+        one.reset()
+        for a in acts:
+            o1, d1, i1 = one.step(a)
+            for p in range(parts):
+                env.step_part_async(p, a[p * per:(p + 1) * per].contiguous())
+            env.wait()
+            torch.cuda.synchronize()
+            for p in range(parts):
+                part = env.parts[p]
+                sl = slice(p * per, (p + 1) * per)
+                assert torch.equal(part._obs, o1[sl]) and torch.equal(part._flags, i1["flags"][sl])
+                assert torch.equal(part._reward, i1["reward"][sl]) and torch.equal(part.positions, one.positions[:, sl])
+        env.close()
+    with pytest.raises(ValueError):
+        PipelinedTilerSliderEnv(1001, parts=2, **kw)

@@ -12,11 +12,12 @@ from .factory import TilerSliderEnvFactory, simple_level
 from .gym_wrapper import GymVecTilerSlider
 from .levels import ImageLoader, Level, pack_levels, parse_board_string
 from .moves import Move
+from .pipelined import PipelinedTilerSliderEnv
 from .render import TextRender
 from .vec_env import StepInfo, VecTilerSliderEnv
 
 __version__ = "0.1.0"
 __all__ = ["GameState", "Move", "TilerSliderEnv", "TilerSliderEnvFactory", "ImageLoader", "TextRender",
-           "VecTilerSliderEnv",
+           "VecTilerSliderEnv", "PipelinedTilerSliderEnv",
            "StepInfo", "GymVecTilerSlider", "Level", "pack_levels", "parse_board_string", "simple_level", "build_library",
            "TilerSliderLibraryError"]

@@ -398,15 +398,19 @@ class VecTilerSliderEnv:
             raise ValueError("actions must be Move values 0..3")  # state.py:43-45
         return self._obs, self._done.view(torch.bool), self._info()
 
-    def step_async(self, act=None):
-        """The bare launch: one ts_step on the current stream, no validation, no sync.
-        `act` is a uint8 device tensor [N] (default: the env's own action buffer)."""
+    def step_async(self, act=None, stream=None):
+        """The bare launch: one ts_step on the current stream (or on `stream`, a torch.cuda.Stream), no
+        validation, no sync.  `act` is a uint8 device tensor [N] (default: the env's own action buffer)."""
         a = self._actions if act is None else act
         if len(self._obs_ring) > 1:  # next observation buffer: the previous one stays intact
             self._obs_slot = (self._obs_slot + 1) % len(self._obs_ring)
             self._obs, self._out = self._obs_ring[self._obs_slot], self._outs[self._obs_slot]
-        self._call("ts_step", C.byref(self._dims), C.byref(self._state), a.data_ptr(), self._mode,
-                   C.byref(self._out))
+        if stream is None:
+            self._call("ts_step", C.byref(self._dims), C.byref(self._state), a.data_ptr(), self._mode,
+                       C.byref(self._out))
+        else:  # no stream context switch from Python: the handle goes straight into the C-ABI
+            _cabi.check(_cabi.lib().ts_step(C.byref(self._dims), C.byref(self._state), a.data_ptr(), self._mode,
+                                            C.byref(self._out), stream.cuda_stream), "ts_step")
 
     def capture_steps(self, action_buffers):
         """Capture one ts_step per action buffer (uint8 device tensors [N], read at replay time)
