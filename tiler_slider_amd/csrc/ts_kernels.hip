@@ -164,15 +164,30 @@ __device__ __forceinline__ f32x4 bytes_to_f4(uint32_t w) {
   return v;
 }
 
-// NT = nontemporal: for launches whose output cannot stay in the 256 MiB Infinity Cache the
-// streaming hint is worth +17 % (5.0 -> 5.9 TB/s at 4M 4x4 boards); for cache-resident
-// launches it costs 12 % (33.7 -> 37.9 us at 1M boards).  Chosen per launch on the host.
+// Store policy of the big output streams (observation, one-hot), chosen per launch on the host:
+//  * NT (nontemporal) for launches whose output cannot stay in the 256 MiB Infinity Cache: +17 % there
+//    (5.0 -> 5.9 TB/s at 4M 4x4 boards), -12 % on cache-resident launches (33.7 -> 37.9 us at 1M boards);
+//  * cache-resident launches store at AGENT scope (`sc1`: written through the XCD's L2 instead of left dirty
+//    in it).  With plain stores up to 32 MB of dirty lines sit in the eight L2s when the last wave retires, and
+//    the kernel cannot end before they are written back - cfg1 32.0 -> 30.1 us, 3x3 20.5 -> 18.1, 262,144 4x4
+//    boards 10.7 -> 9.7, cfg4's shape at 65,536 boards 30.8 -> 29.3 (profiles/r02_cfg1_small_ops.log).  Beyond the
+//    cache the same bit loses badly (cfg4 121 -> 278 us), so NT launches keep the nontemporal builtin.
+// There is no builtin for a scoped 128-bit store, hence the instruction itself.  No "memory" clobber: the
+// statement reads registers only, nothing in these kernels reads the outputs back, and an untracked VMEM store
+// can only make the compiler's s_waitcnt vmcnt(N) waits longer than needed (vmcnt retires in issue order on gfx9).
+__device__ __forceinline__ void store16_agent_scope(void *dst, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v));
+}
+__device__ __forceinline__ void store4_agent_scope(void *dst, uint32_t v) {
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v));
+}
+
 template <bool NT>
 __device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
   if constexpr (NT)
     __builtin_nontemporal_store(v, dst);
   else
-    *dst = v;
+    store16_agent_scope(dst, v);
 }
 
 // Streams `nfl` bytes of an LDS byte image out as float32, 16 B per lane per instruction.
@@ -222,7 +237,12 @@ __device__ __forceinline__ void emit_bytes_raw(const unsigned char *img, uint8_t
 #if TS_ABLATE == 1
   if (nbytes == -12345)
 #endif
-  for (int q = lane; q < nv; q += kWave) d[q] = src[q];
+  for (int q = lane; q < nv; q += kWave) {  // the uint8 observation never exceeds the cache-resident policy's range
+    if constexpr (VEC == 16)
+      store16_agent_scope(&d[q], __builtin_bit_cast(f32x4, src[q]));
+    else
+      store4_agent_scope(&d[q], src[q]);
+  }
   const int tail = nbytes - nv * VEC;  // only on a ragged last tile
   if (lane < tail) dst[nv * VEC + lane] = img[nv * VEC + lane];
 }

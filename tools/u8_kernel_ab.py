@@ -4,7 +4,7 @@ import torch, bench
 from tiler_slider_amd import VecTilerSliderEnv, _cabi
 L = _cabi.lib()
 dev = torch.device("cuda", 0)
-for n in (1 << 20, 1 << 21, 1 << 22):
+for n in (1 << 18, 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24):
     for kw, tag in ((dict(obs_dtype="uint8"), "u8 obs"), (dict(obs_dtype="uint8", with_reward=True, with_valid_moves=True), "u8 obs + reward + mask")):
         env = VecTilerSliderEnv.random(n, size=4, num_tiles=2, num_obstacles=2, seed=1, multi_color=True, max_steps=2**30, auto_reset=True, device=dev, **kw)
         env.reset()
