@@ -4,8 +4,8 @@ A step kernel spends its first ~2 us on state loads and the transition of the fi
 nothing is stored yet — and as long draining at the end.  A learner that works on one half of its
 environments while the other half steps (the usual double-buffered actor loop) can let those ramps
 overlap: part A's next launch starts while part B's observation stores are still streaming.  Measured on
-MI355X (bench.py `pipelined_halves`, eager launches, no join between steps): 1,048,576 4x4 boards 32.1 -> 29.9 us
-per step of all boards with two parts; 5x5 + one-hot + reward 122.5 -> 118.4; 15x15 / 32 tiles 120.6 -> 125.1
+MI355X (bench.py `pipelined_halves`, eager launches, no join between steps): 1,048,576 4x4 boards 29.9 -> 26.7 us
+per step of all boards with two parts (32.1 -> 29.9 before the cache-resident stores went to agent scope); 5x5 + one-hot + reward 122.5 -> 118.4; 15x15 / 32 tiles 120.6 -> 125.1
 (worse: that launch is HBM-bound for 120 us, its ramps are a small share, and two launches disturb each other's
 store pattern); four parts and more lose everywhere.  The synchronous reference API (obs of ALL boards before
 the next action) cannot use this: there every step joins the parts, and nothing overlaps.
