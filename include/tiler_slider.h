@@ -223,7 +223,7 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
  *       5x5 with n_tiles == n_targets <= 8 run two boards per lane (k_multi: half the narrow
  *       state accesses and half the waves of the one-board-per-lane kernel; needs an even
  *       n_boards and 2-element-aligned rows, else the one-board kernel runs).  Default
- *       524288 (measured break-even on MI355X); 0 = whenever applicable; INT64_MAX = never.
+ *       1048576 (measured break-even on MI355X); 0 = whenever applicable; INT64_MAX = never.
  * value >= 0 sets the knob, value < 0 only queries.  Returns the value before the call, or
  * -1 for an unknown key.  Thread-safe (one atomic per knob). */
 #define TS_TUNE_MULTI_MIN_BOARDS 0

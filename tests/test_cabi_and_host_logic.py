@@ -39,7 +39,7 @@ def test_launch_policy_knob():
     from tiler_slider_amd import _cabi
     L = _cabi.lib()
     default = L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, -1)
-    assert default == 524288
+    assert default == 1048576
     assert L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, 0) == default
     assert L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, -1) == 0
     assert L.ts_tuning(_cabi.TUNE_MULTI_MIN_BOARDS, default) == 0

@@ -1,7 +1,7 @@
 """k_multi — the cache-resident kernel that runs two boards per lane (boards up to 5x5, tile count
 == target count <= 8, even batch, no one-hot) — against the reference goldens and the oracle.
 
-The library launches it from ts_tuning(TS_TUNE_MULTI_MIN_BOARDS) boards on (default 524288, where the
+The library launches it from ts_tuning(TS_TUNE_MULTI_MIN_BOARDS) boards on (default 1048576, where the
 full-size tests of test_gpu_parity.py reach it); here the knob is set to 0, so every applicable
 launch of these small batches takes it, and restored afterwards.  Each comparison is bit-exact."""
 import numpy as np

@@ -71,7 +71,7 @@
 #define TS_MULTI_G 2
 #endif
 #ifndef TS_MULTI_MIN_BOARDS  // below this many boards k_small's four times as many waves fill the chip better
-#define TS_MULTI_MIN_BOARDS 524288
+#define TS_MULTI_MIN_BOARDS 1048576
 #endif
 #ifndef TS_WAVES_PER_BLOCK
 #define TS_WAVES_PER_BLOCK 4

@@ -70,4 +70,4 @@ for parts in (1, 2, 3, 4, 8):
         res.append(e0.elapsed_time(e1) * 1e3 / (10 * STEPS))
     print(f"{n} {S}x{S} boards as {parts} part(s) on {parts} stream(s), hipGraph replay: {sorted(res)[2]:7.2f} us per step of all boards", flush=True)
     del graph, envs, acts, streams
-L.ts_tuning(0, 524288)
+L.ts_tuning(0, 1048576)

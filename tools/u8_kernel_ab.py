@@ -21,5 +21,5 @@ for n in (1 << 18, 1 << 20, 1 << 21, 1 << 22, 1 << 23, 1 << 24):
                 e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) * 5)
             out.append(sorted(ts)[2])
-        L.ts_tuning(0, 524288)
+        L.ts_tuning(0, 1048576)
         print(f"{n:8d} boards, {tag:24s}: k_small {out[0]:6.2f} us   k_multi {out[1]:6.2f} us", flush=True)
