@@ -175,8 +175,14 @@ __device__ __forceinline__ f32x4 bytes_to_f4(uint32_t w) {
 // There is no builtin for a scoped 128-bit store, hence the instruction itself.  No "memory" clobber: the
 // statement reads registers only, nothing in these kernels reads the outputs back, and an untracked VMEM store
 // can only make the compiler's s_waitcnt vmcnt(N) waits longer than needed (vmcnt retires in issue order on gfx9).
+// The two wait states BEHIND the store are part of it: on gfx940+ a VALU instruction must not overwrite a data
+// register of a FLAT / global store of more than 64 bits within two wait states of the store (the hardware reads the
+// last data registers that late; LLVM's hazard recognizer pads its own stores - checkVALUHazards, "12-dword store" -
+// but cannot see into an asm statement, and to the register allocator the operands are dead right behind it).  Found
+// the hard way: an unrolled emit loop reused the data registers for the next conversion one instruction after the
+// store and the .w component of some lanes came out with the NEXT store's value (tools/check_variants_vs_oracle.py).
 __device__ __forceinline__ void store16_agent_scope(void *dst, f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v));
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v));
 }
 __device__ __forceinline__ void store4_agent_scope(void *dst, uint32_t v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v));
@@ -217,6 +223,8 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
       }
     }
 #else
+    // (the agent-scope store of cache-resident launches is an asm statement - convergent to the compiler - so the
+    // pragma only unrolls the nontemporal instantiation; a hand-unrolled agent-scope loop measured the same)
 #pragma unroll TS_EMIT_UNROLL
     for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
 #endif
