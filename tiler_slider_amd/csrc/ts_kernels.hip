@@ -223,10 +223,14 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
       }
     }
 #else
-    // (the agent-scope store of cache-resident launches is an asm statement - convergent to the compiler - so the
-    // pragma only unrolls the nontemporal instantiation; a hand-unrolled agent-scope loop measured the same)
+    if constexpr (NT) {
 #pragma unroll TS_EMIT_UNROLL
-    for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+      for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+    } else {
+      // the agent-scope store is an asm statement - a convergent operation to the compiler, which does not unroll a
+      // loop around one with a run-time remainder; a hand-unrolled version measured the same (30.2 vs 30.2 us at cfg1)
+      for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+    }
 #endif
   }
   const int tail = nfl & 3;  // only on the last, partial tile of odd-sized boards
@@ -711,9 +715,9 @@ template <int G> struct MultiPack;
 template <> struct MultiPack<2> { using bytes_t = uint16_t; using words_t = uint2; };
 template <> struct MultiPack<4> { using bytes_t = uint32_t; using words_t = uint4; };
 __device__ __forceinline__ uint32_t word_of(const uint2 &v, int g) { return g == 0 ? v.x : v.y; }
-__device__ __forceinline__ uint32_t word_of(const uint4 &v, int g) { return g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w; }
+[[maybe_unused]] __device__ __forceinline__ uint32_t word_of(const uint4 &v, int g) { return g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w; }
 __device__ __forceinline__ void set_word(uint2 &v, int g, uint32_t x) { (g == 0 ? v.x : v.y) = x; }
-__device__ __forceinline__ void set_word(uint4 &v, int g, uint32_t x) { (g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w) = x; }
+[[maybe_unused]] __device__ __forceinline__ void set_word(uint4 &v, int g, uint32_t x) { (g == 0 ? v.x : g == 1 ? v.y : g == 2 ? v.z : v.w) = x; }
 
 template <int S, int TFIX, bool EXTRAS, int G>
 __global__ __launch_bounds__(256) void k_multi(const KArgs a) {
