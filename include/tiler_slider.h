@@ -224,9 +224,15 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
  *       state accesses and half the waves of the one-board-per-lane kernel; needs an even
  *       n_boards and 2-element-aligned rows, else the one-board kernel runs).  Default
  *       1048576 (measured break-even on MI355X); 0 = whenever applicable; INT64_MAX = never.
+ *   TS_TUNE_NT_THRESHOLD_BYTES  bytes of large outputs (observation, one-hot planes, uint8 observation) per
+ *       launch above which a launch counts as "beyond the Infinity Cache": nontemporal stores, one-wave
+ *       blocks, bounded residency, half waves (different instantiations of the same kernels).  Default
+ *       268435456 (the 256 MiB Infinity Cache of MI355X); 0 = every launch takes the out-of-cache kernels
+ *       (the parity tests use this to cover them at small batch sizes).
  * value >= 0 sets the knob, value < 0 only queries.  Returns the value before the call, or
  * -1 for an unknown key.  Thread-safe (one atomic per knob). */
 #define TS_TUNE_MULTI_MIN_BOARDS 0
+#define TS_TUNE_NT_THRESHOLD_BYTES 1
 int64_t ts_tuning(int32_t key, int64_t value);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */

@@ -34,11 +34,20 @@ class _OracleShardEnv:
         self._tgt = torch.from_numpy(tgt.view(np.uint8 if S <= 16 else np.int16)).to(cell)
         self._pos = torch.from_numpy(self.b.pos.view(np.uint8 if S <= 16 else np.int16))  # shares the oracle's buffer
         self._obs = torch.from_numpy(self.b.reset())
-        self._lines = None
+        # per-level line tables above 8x8 ([n, 32] words up to 16x16, [n, 128] above: include/tiler_slider.h).  The
+        # oracle encoder needs none; the values here are a function of the GLOBAL board index, so the test can see
+        # that every rank's (padded) records landed in the right rows of the gathered table.
+        words = 0 if S <= 8 else 32 if S <= 16 else 128
+        self._lines = _fake_lines(lo, hi, words) if words else None
 
     def step(self, orc, i):
         act = orc.fill_actions(self.num_envs, seed=5, step_index=i, board_offset=self.lo)
         self._obs.copy_(torch.from_numpy(self.b.step(act, mode=orc.MODE_AUTORESET)["obs"]).to(self._obs.dtype))
+
+
+def _fake_lines(lo, hi, words):
+    g = torch.arange(lo, hi, dtype=torch.int64)[:, None] * 1000 + torch.arange(words, dtype=torch.int64)[None, :]
+    return g.to(torch.int32)
 
 
 def _oracle_encode(env, shard):
@@ -68,6 +77,15 @@ def _worker(rank, world, port, case, q):
     g8 = ObservationGatherer(env8, world, encode_fn=_oracle_encode, expand_fn=_cpu_expand)
     ok = g.counts == [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
     ok &= g.equal == (total % world == 0) and g.obs_all.shape[0] == total
+    if env._lines is not None:  # the once-gathered line tables: rank r's records at rows r * nmax ..., padding rows zero
+        ok &= g.lines_flat.shape == (world * g.nmax, env._lines.shape[1])
+        for r in range(world):
+            rlo, rhi = shard_bounds(total, world, r)
+            rows = g.lines_flat[r * g.nmax:(r + 1) * g.nmax]
+            ok &= torch.equal(rows[:rhi - rlo], _fake_lines(rlo, rhi, env._lines.shape[1]))
+            ok &= bool((rows[rhi - rlo:] == 0).all())
+    else:
+        ok &= g.lines_flat is None
     whole = _OracleShardEnv(orc, case, 0, total)  # the single-process batch
     for i in range(STEPS):
         env.step(orc, i)
@@ -83,6 +101,14 @@ def _worker(rank, world, port, case, q):
         hc = g8.gather_u8_and_expand(async_op=True)
         ok &= torch.equal(ha.wait(), whole._obs) and torch.equal(hb.wait().clone(), whole._obs)
         ok &= torch.equal(hc.wait(), whole._obs) and ha.wait() is g.obs_all  # wait() is idempotent
+        # the compact hand-off sends a SNAPSHOT of the cell ids: stepping before wait() must not change what arrives
+        # (the pre-fix code sent env._pos itself, which the next step rewrites in place)
+        hd = g.gather_compact_and_encode(async_op=True)
+        before = whole._obs.clone()
+        env.step(orc, 100 + i)
+        ok &= torch.equal(hd.wait(), before)
+        whole.step(orc, 100 + i)
+        env8.step(orc, 100 + i)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -107,7 +133,18 @@ def test_two_rank_gather_matches_single_process(oracle, case):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, case, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = sorted(q.get(timeout=180) for _ in procs)
+    results, waited = [], 0.0
+    while len(results) < len(procs) and waited < 180:  # a rank that died will never report: do not sit out the timeout
+        try:
+            results.append(q.get(timeout=1.0))
+        except Exception:
+            waited += 1.0
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    if len(results) < len(procs):
+        for p in procs:
+            p.kill()
+    results.sort()
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

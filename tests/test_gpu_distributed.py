@@ -1,0 +1,169 @@
+"""The multi-rank hand-off (tiler_slider_amd.distributed) on REAL VecTilerSliderEnv buffers on the GPU.
+
+An 8-GPU node is not available to these tests, so the N > 1 code is exercised two ways on one card:
+  * world_size = 1 over RCCL ("nccl"): the exact overlapped loop of bench.py (step k+1 is launched before
+    gather k is waited for, the collective runs on RCCL's own stream) for all three hand-offs, every
+    gathered tensor compared with a clone of env.encode() taken at that step — uint8 cells (4x4), the
+    per-level `lines` tables (12x12) and int16 cells with the wide tables (20x20);
+  * several ranks as THREADS of this process, each with its own real shard environment and gatherer, the
+    collective replaced by an in-process loopback (ObservationGatherer(all_gather_fn=...)): unequal shards,
+    odd board sizes (where 12*S*S*offset is not a multiple of 16: ts_encode / ts_expand_u8 refuse such
+    pointers, so the gatherer must only ever hand them whole, base-aligned buffers), `lines`, int16 cells.
+Everything is compared with one environment over ALL boards (levels are a function of the global board index).
+"""
+import os
+import socket
+import threading
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ACTION_SEED = 0xAC710005
+# name: (S, T, K, total boards)
+SHAPES = {"s4_u8cells": (4, 2, 2, 40_000), "s12_lines": (12, 8, 16, 6_000), "s20_wide_i16": (20, 6, 30, 3_000)}
+
+
+@pytest.fixture(scope="module")
+def rccl_world1():
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _actions(torch, env, step, lo=0):
+    from tiler_slider_amd import _cabi
+    a = torch.empty(env.num_envs, dtype=torch.uint8, device=env.device)
+    stream = torch.cuda.current_stream(env.device).cuda_stream
+    _cabi.check(_cabi.lib().ts_fill_actions(env.num_envs, ACTION_SEED, lo, step, a.data_ptr(), stream), "ts_fill_actions")
+    return a
+
+
+@pytest.mark.parametrize("shape", sorted(SHAPES))
+def test_overlapped_gathers_over_rccl_world1(rccl_world1, shape):
+    """bench.py's overlapped() loop, verbatim, on a real environment: gather k is issued async behind step k,
+    step k+1 is launched BEFORE gather k is waited for.  The compact form must deliver the cells of step k
+    (it sends a snapshot; the pre-fix code sent `pos` itself, which step k+1 rewrites in place)."""
+    import torch
+    from tiler_slider_amd import VecTilerSliderEnv
+    from tiler_slider_amd.distributed import ObservationGatherer
+    S, T, K, N = SHAPES[shape]
+    kw = dict(size=S, num_tiles=T, num_obstacles=K, seed=77, multi_color=True, max_steps=5, auto_reset=True, obs_buffers=2)
+    e32 = VecTilerSliderEnv.random(N, **kw)
+    e8 = VecTilerSliderEnv.random(N, obs_dtype="uint8", **kw)
+    assert (e32._lines is not None) == (S > 8) and e32._pos.dtype == (torch.uint8 if S <= 16 else torch.int16)
+    g32, g8 = ObservationGatherer(e32, 1), ObservationGatherer(e8, 1)
+    assert g32.counts == [N] and g32.equal and (g32.lines_flat is not None) == (S > 8)
+    modes = [("obs_f32", e32, lambda a: g32.gather_observations(e32._obs, async_op=a)),
+             ("compact", e32, lambda a: g32.gather_compact_and_encode(async_op=a)),
+             ("obs_u8", e8, lambda a: g8.gather_u8_and_expand(e8._obs, async_op=a))]
+    steps = 8
+    for name, env, fn in modes:
+        env.reset()
+        acts = [_actions(torch, env, i) for i in range(steps)]
+        assert torch.equal(fn(False), env.encode(torch.empty_like(g32.obs_all))), (name, "blocking")
+        expect, prev = [], None
+        for i in range(steps):
+            env.step_async(acts[i])
+            expect.append(env.encode(torch.empty_like(g32.obs_all)))  # float32 image of the boards after step i
+            if prev is not None:
+                got = prev.wait()
+                assert torch.equal(got, expect[i - 1]), (name, "gather", i - 1)
+            prev = fn(True)
+        assert torch.equal(prev.wait(), expect[-1]), (name, "last")
+        torch.cuda.synchronize()
+    with pytest.raises(ValueError):  # async gather of a single-buffered environment would race with the next step
+        one = VecTilerSliderEnv.random(64, size=4, num_tiles=2, num_obstacles=2)
+        one.reset()
+        ObservationGatherer(one, 1).gather_observations(async_op=True)
+
+
+class _Loopback:
+    """all_gather_fn for ranks that are threads of one process on one GPU (test only)."""
+
+    def __init__(self, world):
+        self.world, self.bar, self.slots = world, threading.Barrier(world), [None] * world
+
+    def fn(self, rank):
+        import torch
+
+        def all_gather(out_u8, shard_u8, async_op):
+            torch.cuda.synchronize()  # this rank's shard is complete
+            self.slots[rank] = shard_u8
+            self.bar.wait(timeout=120)
+            nb = shard_u8.numel()
+            for r in range(self.world):
+                assert self.slots[r].numel() == nb, "all-gather pieces must have equal sizes"
+                out_u8[r * nb:(r + 1) * nb].copy_(self.slots[r])
+            torch.cuda.synchronize()
+            self.bar.wait(timeout=120)  # nobody reuses its send buffer before every rank has copied it
+            return None
+        return all_gather
+
+
+# name: (S, T, K, total, world): unequal shards on odd sizes (5x5: 300 B per board, 9x9: 972 B: offsets off 16 B),
+# a three-way split, lines tables, int16 cells; one equal case
+THREAD_CASES = {"s9_39_38": (9, 4, 5, 77, 2), "s5_unequal": (5, 2, 3, 2001, 2), "s20_i16_unequal": (20, 3, 9, 301, 2),
+                "s15_three_ranks": (15, 32, 24, 1000, 3), "s4_equal_odd_count": (4, 2, 2, 3003, 3), "s3_tiny": (3, 1, 0, 5, 2)}
+
+
+@pytest.mark.parametrize("case", sorted(THREAD_CASES))
+def test_gathers_with_threads_as_ranks(case):
+    import torch
+    from tiler_slider_amd import VecTilerSliderEnv
+    from tiler_slider_amd.distributed import ObservationGatherer, make_sharded_env, shard_bounds
+    assert torch.cuda.is_available()
+    S, T, K, total, world = THREAD_CASES[case]
+    kw = dict(size=S, num_tiles=T, num_obstacles=K, seed=31, multi_color=True, max_steps=4, auto_reset=True)
+    whole = VecTilerSliderEnv.random(total, **kw)
+    whole.reset()
+    steps = 5
+    expect = []
+    for i in range(steps):
+        whole.step_async(_actions(torch, whole, i))
+        expect.append(whole.encode().clone())
+    torch.cuda.synchronize()
+    loop = _Loopback(world)
+    errors = []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            lo, hi = shard_bounds(total, world, rank)
+            e32 = make_sharded_env(total, rank, world, obs_buffers=2, **kw)
+            e8 = make_sharded_env(total, rank, world, obs_buffers=2, obs_dtype="uint8", **kw)
+            g32 = ObservationGatherer(e32, world, all_gather_fn=loop.fn(rank))
+            g8 = ObservationGatherer(e8, world, all_gather_fn=loop.fn(rank))
+            assert g32.counts == [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
+            assert g32.equal == (total % world == 0) and g32.obs_all.shape[0] == total
+            e32.reset(), e8.reset()
+            for i in range(steps):
+                e32.step_async(_actions(torch, e32, i, lo))
+                e8.step_async(_actions(torch, e8, i, lo))
+                for name, got in (("obs_f32", g32.gather_observations(e32._obs)),
+                                  ("compact", g32.gather_compact_and_encode()),
+                                  ("obs_u8", g8.gather_u8_and_expand(e8._obs)),
+                                  ("compact async", g32.gather_compact_and_encode(async_op=True).wait()),
+                                  ("obs_u8 async", g8.gather_u8_and_expand(e8._obs, async_op=True).wait())):
+                    torch.cuda.synchronize()
+                    assert torch.equal(got, expect[i]), (case, rank, i, name)
+        except BaseException as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((rank, repr(e)))
+            loop.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)

@@ -103,9 +103,27 @@ RANDOM_SHAPES = [
 ]
 
 
+@pytest.fixture
+def out_of_cache_kernels():
+    """Every launch takes the out-of-cache instantiations (nontemporal stores, one-wave blocks, bounded residency,
+    half waves) for the duration of a test: ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES, 0)."""
+    from tiler_slider_amd import _cabi
+    L = _cabi.lib()
+    before = L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, 0)
+    yield
+    L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, before)
+
+
+@pytest.mark.parametrize("S,T,K,mc,N,max_steps", RANDOM_SHAPES)
+def test_random_boards_vs_oracle_out_of_cache_kernels(torch_cuda, oracle, out_of_cache_kernels, S, T, K, mc, N, max_steps):
+    """The same shapes through the kernels of launches beyond the Infinity Cache, which the default policy only picks
+    from ~256 MiB of output on — plus the uint8-observation environment, whose byte stream has a nontemporal form too."""
+    test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, True, steps=8, with_u8=True)
+
+
 @pytest.mark.parametrize("S,T,K,mc,N,max_steps", RANDOM_SHAPES)
 @pytest.mark.parametrize("autoreset", [False, True])
-def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, autoreset):
+def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, autoreset, steps=24, with_u8=False):
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv
     if K + 2 * T <= S * S:
@@ -126,8 +144,13 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     want0 = ref.reset()
     np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
     np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
+    env8 = None
+    if with_u8:
+        env8 = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps, auto_reset=autoreset,
+                                             obs_dtype="uint8")
+        np.testing.assert_array_equal(env8.reset().cpu().numpy(), want0.astype(np.uint8))
     mode = oracle.MODE_AUTORESET if autoreset else oracle.MODE_STRICT
-    for step in range(24):
+    for step in range(steps):
         act = oracle.fill_actions(N, seed=77 + S, step_index=step)
         if step == 5:
             act[::13] = 9  # invalid action bytes: flagged, board untouched
@@ -143,6 +166,10 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
         np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
         np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
         np.testing.assert_array_equal(env._valid.cpu().numpy(), want["valid"], err_msg=ctx)
+        if env8 is not None:
+            obs8, _, info8 = env8.step(torch.from_numpy(act))
+            np.testing.assert_array_equal(obs8.cpu().numpy(), want["obs"].astype(np.uint8), err_msg=ctx)
+            np.testing.assert_array_equal(info8["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
     # stand-alone entry points on the final state
     np.testing.assert_array_equal(env.get_valid_moves().cpu().numpy(),
                                   (ref.valid_moves()[:, None] >> np.arange(4)) & 1 != 0)
@@ -153,7 +180,7 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
     np.testing.assert_array_equal(plain.encode().cpu().numpy(), ref.encode())
     np.testing.assert_array_equal(plain.is_won().cpu().numpy(), ref.won() != 0)
-    if not autoreset and max_steps < 24:  # strict mode: every board timed out and was then flagged
+    if not autoreset and max_steps < steps:  # strict mode: every board timed out and was then flagged
         assert (ref.done != 0).all()
 
 
@@ -203,20 +230,21 @@ def test_generator_and_actions_match_twin(torch_cuda, oracle):
             assert all(((int(blk[p >> 5, n]) >> (p & 31)) & 1) == 0 for p in col)
 
 
-@pytest.mark.parametrize("S,T,K,N", [(4, 2, 2, 1 << 20), (5, 2, 3, 1 << 20), (15, 32, 24, 1 << 18), (4, 2, 2, 1 << 22),
-                                     (6, 3, 4, 1 << 20)])
-def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N):
+@pytest.mark.parametrize("S,T,K,N,onehot", [(4, 2, 2, 1 << 20, False), (5, 2, 3, 1 << 20, True), (15, 32, 24, 1 << 18, False),
+                                            (4, 2, 2, 1 << 22, False), (6, 3, 4, 1 << 20, False)])
+def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N, onehot):
     """BASELINE.json configs 1, 2 and 4 at full size, the 4M-board sibling of config 1 and a 6x6
     batch beyond the Infinity Cache (two-pass image in half waves): a complete oracle replay of every
     board for a few steps (the C oracle is fast enough) — with the optional outputs and, on a
     second environment, without them, so that the out-of-cache launch policies of the plain kernels
-    (one-wave blocks, bounded residency, half waves) are exercised at the sizes where they apply —
-    then properties that do not need the oracle: sliding twice in one direction is idempotent,
+    (one-wave blocks, bounded residency, half waves) are exercised at the sizes where they apply; config 2 with
+    its one-hot planes (524 MB per step), i.e. the fused step + one-hot + reward launch of the bench line, plane
+    for plane — then properties that do not need the oracle: sliding twice in one direction is idempotent,
     tile / obstacle counts are conserved in the observation, and autoreset keeps every board live."""
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv
     env = VecTilerSliderEnv.random(N, size=S, num_tiles=T, num_obstacles=K, seed=0x715311DE, multi_color=True,
-                                   max_steps=2**30, auto_reset=True, with_reward=True)
+                                   max_steps=2**30, auto_reset=True, with_reward=True, with_onehot=onehot)
     plain = VecTilerSliderEnv.from_arrays(S, env._blk, env._init, env._tgt, multi_color=True, max_steps=2**30, auto_reset=True)
     blk = env._blk.cpu().numpy().view(np.uint32)
     ref = oracle.OracleBatch(S, True, 2**30, blk, env._init.cpu().numpy(), env._tgt.cpu().numpy())
@@ -228,11 +256,13 @@ def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N):
     for step in range(steps):
         act = oracle.fill_actions(N, seed=0xAC710005, step_index=step)
         obs, done, info = env.step(torch.from_numpy(act))
-        want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True)
+        want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True, onehot=onehot)
         assert np.array_equal(env.positions.cpu().numpy(), ref.pos)
         assert np.array_equal(info["flags"].cpu().numpy(), want["flags"])
         assert np.array_equal(info["reward"].cpu().numpy(), want["reward"])
         assert np.array_equal(obs.cpu().numpy(), want["obs"])
+        if onehot:
+            assert np.array_equal(info["onehot"].cpu().numpy(), want["onehot"]), step
         pobs, pdone, pinfo = plain.step(torch.from_numpy(act))
         assert np.array_equal(plain.positions.cpu().numpy(), ref.pos)
         assert np.array_equal(pinfo["flags"].cpu().numpy(), want["flags"])
@@ -677,6 +707,35 @@ def test_env_reset_rebuilds_from_edited_attributes(torch_cuda):
     assert obs[2, 2, 1] == 1.0 and obs[2, 0, 2] == 1.0 and env.state.current_locations == [(2, 2)]
     _, done, info = env.step(Move.UP)
     assert done is True and info.get("timeout") is True and "success" not in info
+
+
+def test_env_state_is_a_gamestate_over_the_environments_board(torch_cuda):
+    """environment.py:88-94: `env.state` is the GameState the environment steps — moving it moves the environment's
+    board (state.py:120-170), without touching the environment's own step_count / done (environment.py:131-139)."""
+    from tiler_slider_amd import GameState, Move, TilerSliderEnv
+    env = TilerSliderEnv(size=4, blocked_locations=[(1, 0), (2, 3)], initial_locations=[(0, 3), (3, 2)],
+                         target_locations=[(0, 0), (3, 0)], multi_color=True, max_steps=3)
+    env.reset()
+    assert isinstance(env.state, GameState) and env.state.current_locations == [(0, 3), (3, 2)]
+    assert env.state.move_to.shape == (4, 4, 4, 2) and env.state.is_blocked[1, 0] and not env.state.is_blocked[0, 0]
+    # SURVEY 8c scenario 1: R, D, L ... through the state object
+    assert env.state.move(Move.RIGHT) is False and env.state.current_locations == [(0, 3), (3, 3)]
+    assert env.state.move(Move.DOWN) is False and env.state.current_locations == [(1, 3), (3, 3)]
+    assert env.step_count == 0 and env.done is False  # the environment's counters are its own
+    obs, done, info = env.step(Move.LEFT)               # ... and the environment continues from the moved board
+    assert env.state.current_locations == [(1, 1), (3, 0)] and info["step_count"] == 0 and env.step_count == 1
+    assert obs[1, 1, 1] == 1.0 and obs[3, 0, 1] == 2.0 and done is False
+    for m in (Move.UP, Move.LEFT, Move.DOWN):  # more moves through the state than max_steps allows: no latch there
+        env.state.move(m)
+    assert env.state.current_locations == [(0, 0), (3, 0)] and env.state.is_won() is True
+    assert env.step_count == 1 and env.done is False and env.get_info()["is_won"] is True
+    twin = env.state.copy()  # an independent board
+    twin.move(Move.RIGHT)
+    assert env.state.current_locations == [(0, 0), (3, 0)] and twin.current_locations != env.state.current_locations
+    env.state.current_locations = [(0, 3), (3, 2)]  # assignable, as tests/test_state.py:330-363 does
+    assert env.get_valid_moves() == [Move.UP, Move.DOWN, Move.LEFT, Move.RIGHT]
+    env.state.current_locations = [(0, 0), (3, 0)]
+    assert env.get_valid_moves() == [Move.UP, Move.RIGHT]  # (3,0) can go up to (2,0); (0,0) has the obstacle (1,0) below
 
 
 def test_from_arrays_validate(torch_cuda, oracle):

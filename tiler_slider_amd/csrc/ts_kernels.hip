@@ -179,6 +179,7 @@ __device__ __forceinline__ f32x4 bytes_to_f4(uint32_t w) {
 // register of a FLAT / global store of more than 64 bits within two wait states of the store (the hardware reads the
 // last data registers that late; LLVM's hazard recognizer pads its own stores - checkVALUHazards, "12-dword store" -
 // but cannot see into an asm statement, and to the register allocator the operands are dead right behind it).  Found
+// Any future kernel that reads its own output stream back needs a "memory" clobber on these statements.  Found
 // the hard way: an unrolled emit loop reused the data registers for the next conversion one instruction after the
 // store and the .w component of some lanes came out with the NEXT store's value (tools/check_variants_vs_oracle.py).
 __device__ __forceinline__ void store16_agent_scope(void *dst, f32x4 v) {
@@ -239,8 +240,10 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
 
 // Streams `nbytes` of an LDS byte image out unchanged (the uint8 observation).  VEC = 16 needs
 // dst 16-B aligned (k_small: a tile starts at a multiple of 32 boards); VEC = 4 needs 4-B
-// alignment (k_lines: 3*S*S bytes per board times a multiple of 4 boards).
-template <int VEC>
+// alignment (k_lines: 3*S*S bytes per board times a multiple of 4 boards).  Same store policy as the
+// float32 stream: agent scope while the launch's outputs fit the Infinity Cache, nontemporal beyond
+// (a uint8 environment leaves the cache from ~5.6 M 4x4 boards).
+template <int VEC, bool NT>
 __device__ __forceinline__ void emit_bytes_raw(const unsigned char *img, uint8_t *dst, int nbytes, int lane) {
   using vec_t = typename std::conditional<VEC == 16, uint4, uint32_t>::type;
   const int nv = nbytes / VEC;
@@ -249,11 +252,17 @@ __device__ __forceinline__ void emit_bytes_raw(const unsigned char *img, uint8_t
 #if TS_ABLATE == 1
   if (nbytes == -12345)
 #endif
-  for (int q = lane; q < nv; q += kWave) {  // the uint8 observation never exceeds the cache-resident policy's range
-    if constexpr (VEC == 16)
+  for (int q = lane; q < nv; q += kWave) {
+    if constexpr (NT) {
+      if constexpr (VEC == 16)
+        __builtin_nontemporal_store(__builtin_bit_cast(f32x4, src[q]), reinterpret_cast<f32x4 *>(&d[q]));
+      else
+        __builtin_nontemporal_store(src[q], &d[q]);
+    } else if constexpr (VEC == 16) {
       store16_agent_scope(&d[q], __builtin_bit_cast(f32x4, src[q]));
-    else
+    } else {
       store4_agent_scope(&d[q], src[q]);
+    }
   }
   const int tail = nbytes - nv * VEC;  // only on a ragged last tile
   if (lane < tail) dst[nv * VEC + lane] = img[nv * VEC + lane];
@@ -614,7 +623,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
       if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
-      if (a.obs_u8) emit_bytes_raw<16>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
+      if (a.obs_u8) emit_bytes_raw<16, NT>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
     }
   }
 
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(256) void k_multi(const KArgs a) {
   if (a.obs || a.obs_u8) {
     wave_sync();
     if (a.obs) emit_bytes_as_f32<false>(img, a.obs + n0 * (3 * C), nb * 3 * C, lane);
-    if (a.obs_u8) emit_bytes_raw<16>(img, a.obs_u8 + n0 * (3 * C), nb * 3 * C, lane);
+    if (a.obs_u8) emit_bytes_raw<16, false>(img, a.obs_u8 + n0 * (3 * C), nb * 3 * C, lane);
   }
 }
 
@@ -1214,7 +1223,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
     }
     wave_sync();
     if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
-    if (a.obs_u8) emit_bytes_raw<4>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
+    if (a.obs_u8) emit_bytes_raw<4, NT>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 
   // ---- build-defined one-hot planes [board][Ch][S][S] (include/tiler_slider.h) ----
@@ -1456,6 +1465,7 @@ __global__ __launch_bounds__(256) void k_fill_actions(uint8_t *actions, int64_t 
 // ------------------------------------------------------------------------------------------
 thread_local int32_t t_last_hip_error = 0;
 std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_TUNE_MULTI_MIN_BOARDS)
+std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
 
 int32_t check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
@@ -1681,8 +1691,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   a.max_steps = d->max_steps;
   a.onehot_ch = onehot_channels(d);
   {
-    const uint64_t per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);  // (obs_u8 stores are plain)
-    a.nt = per_board * (uint64_t)d->n_boards > (uint64_t)TS_NT_THRESHOLD_MB * 1024ull * 1024ull ? 1u : 0u;
+    const uint64_t per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
+    a.nt = per_board * (uint64_t)d->n_boards > (uint64_t)g_nt_threshold_bytes.load(std::memory_order_relaxed) ? 1u : 0u;
   }
   hipStream_t hs = (hipStream_t)stream;
 
@@ -1710,7 +1720,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_stage_off = align16((uint32_t)(small_obs_boards(C) * 3 * C));
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
-    const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull);
+    const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board);
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     apply_launch_hint(res, d->launch_hint);
@@ -1744,7 +1754,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
     a.bpw = (a.nt && TS_LINES_OOC_BPW > 0) ? TS_LINES_OOC_BPW : kLinesBPW;
     Residency res = ooc_residency(a.nt != 0, true, false,
-                                        (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull)), T);
+                                        (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)), T);
     apply_launch_hint(res, d->launch_hint);
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
@@ -1895,7 +1905,7 @@ int32_t ts_expand_u8(const uint8_t *src, float *dst, int64_t count, void *stream
   if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
   hipStream_t hs = (hipStream_t)stream;
   if (n4 > 0) {
-    const bool nt = (uint64_t)count * 4ull > (uint64_t)TS_NT_THRESHOLD_MB * 1024ull * 1024ull;
+    const bool nt = (uint64_t)count * 4ull > (uint64_t)g_nt_threshold_bytes.load(std::memory_order_relaxed);
     if (nt)
       hipLaunchKernelGGL(k_expand_u8<true>, dim3((uint32_t)blocks), dim3(256), 0, hs, (const uint32_t *)src, (f32x4 *)dst, n4);
     else
@@ -1935,8 +1945,9 @@ int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void
 }
 
 int64_t ts_tuning(int32_t key, int64_t value) {
-  if (key != TS_TUNE_MULTI_MIN_BOARDS) return -1;
-  return value >= 0 ? g_multi_min_boards.exchange(value) : g_multi_min_boards.load();
+  std::atomic<int64_t> *knob = key == TS_TUNE_MULTI_MIN_BOARDS ? &g_multi_min_boards : key == TS_TUNE_NT_THRESHOLD_BYTES ? &g_nt_threshold_bytes : nullptr;
+  if (!knob) return -1;
+  return value >= 0 ? knob->exchange(value) : knob->load();
 }
 
 int32_t ts_lines_words(int32_t size) { return size < 9 || size > TS_MAX_SIZE ? 0 : lines_record_words(size > 16); }

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _cabi
-from .levels import cell_dtype, pack_levels, unpack_blocked, unpack_cells
+from .levels import cell_dtype, pack_levels, unpack_cells
 from .moves import ALL_MOVES, Move
 from .vec_env import _DONE_MSG, VecTilerSliderEnv
 
@@ -41,6 +41,26 @@ class GameState:
                                       device=device, host_mapped=True)
         self._vec.reset()
         self._move_to = None
+        self._shared = False
+
+    @classmethod
+    def _attached(cls, env):
+        """`env.state` of the TilerSliderEnv adapter: a GameState over the environment's OWN one-board buffers, as in the
+        reference (environment.py:88-94 builds the GameState the environment then steps): `env.state.move()` moves the
+        environment's board, `env.step()` shows up in `env.state.current_locations`."""
+        self = cls.__new__(cls)
+        self.size, self.multi_color, self._device = env.size, env.multi_color, env._device
+        self.target_locations = copy.copy(env.target_locations)
+        self._blocked_locations = [(int(i), int(j)) for i, j in env.blocked_locations]
+        self.is_blocked = np.zeros((env.size, env.size), dtype=bool)
+        for i, j in self._blocked_locations:
+            self.is_blocked[i, j] = True
+        self._vec, self._move_to, self._shared = env._vec, None, True
+        self._refresh()
+        return self
+
+    def _refresh(self):
+        self._locations = unpack_cells(self.size, self._vec.positions[:, 0].numpy())
 
     @property
     def current_locations(self):
@@ -63,11 +83,16 @@ class GameState:
     # -- state.py:120-170
     def move(self, move):
         v = self._vec
-        v._done.zero_()  # GameState has no episode latch: it can keep moving after a win
+        # GameState has no episode latch and no step counter: it can keep moving after a win, and a move made through
+        # `env.state` leaves the environment's own step_count / done alone (the reference keeps those in TilerSliderEnv)
+        keep = (int(v._step_count[0]), int(v._done[0])) if self._shared else None
+        v._done.zero_()
         v._actions[0] = move.value  # buffers are pinned host memory the kernel works on in place
         v.step_async()
         v._sync_if_host()
-        self._locations = unpack_cells(self.size, v.positions[:, 0].numpy())
+        if keep is not None:
+            v._step_count[0], v._done[0] = keep
+        self._refresh()
         return bool(int(v._flags[0]) & _cabi.FLAG_IS_WON)
 
     # -- state.py:172-186
@@ -107,33 +132,6 @@ class GameState:
                 table[:, :, d, 1] = dest[d] % S
             self._move_to = table
         return self._move_to
-
-
-class _BoardView:
-    """`env.state` of the adapter: the attributes reference drivers read (display.py:59-70)."""
-
-    def __init__(self, env):
-        self._env = env
-        self.size = env.size
-        self.multi_color = env.multi_color
-        self.target_locations = list(env.target_locations)
-        self.is_blocked = unpack_blocked(env.size, env._vec._blk[:, 0].numpy().view(np.uint32))
-        self.current_locations = []
-        self.refresh()
-
-    def refresh(self):
-        self.current_locations = unpack_cells(self.size, self._env._vec.positions[:, 0].numpy())
-
-    def is_won(self):
-        return bool(self._env._vec.is_won()[0])
-
-    def get_state_array(self):
-        return self._env._vec.encode()[0].numpy().copy()
-
-    def copy(self):
-        blocked = [(int(r), int(c)) for r, c in zip(*np.nonzero(self.is_blocked))]
-        return GameState(self.size, blocked, list(self.current_locations), list(self.target_locations),
-                         self.multi_color, device=self._env._device)
 
 
 class TilerSliderEnv:
@@ -176,7 +174,7 @@ class TilerSliderEnv:
                                           max_steps=self.max_steps, device=self._device, host_mapped=True)
             self._vec_key = key
         obs = self._vec.reset()[0].numpy().copy()  # a fresh array per call, like the reference
-        self.state = _BoardView(self)
+        self.state = GameState._attached(self)
         self.step_count = 0
         self.done = False
         return obs
@@ -193,7 +191,7 @@ class TilerSliderEnv:
         v.step_async()              # one launch ...
         v._sync_if_host()           # ... one stream synchronisation, no device-to-host copies
         flags = int(v._flags[0])
-        self.state.refresh()
+        self.state._refresh()
         info = {"is_won": bool(flags & _cabi.FLAG_IS_WON), "step_count": self.step_count,
                 "invalid_move": bool(flags & _cabi.FLAG_INVALID_MOVE)}
         if flags & _cabi.FLAG_SUCCESS:

@@ -59,5 +59,16 @@ class PipelinedTilerSliderEnv:
             main.wait_stream(self.streams[q])
 
     def close(self):
+        """Joins the parts' streams first: their tensors were allocated on the constructing stream but are written
+        by kernels on the side streams, so the caching allocator may only get them back once those kernels are done."""
+        for s in self.streams:
+            s.synchronize()
         for e in self.parts:
             e.close()
+
+    def __del__(self):
+        try:
+            for s in self.streams:
+                s.synchronize()
+        except Exception:  # interpreter shutdown
+            pass

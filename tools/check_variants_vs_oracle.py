@@ -16,6 +16,79 @@ from oracle import binding as orc  # noqa: E402
 from tiler_slider_amd import VecTilerSliderEnv, _cabi  # noqa: E402
 
 # usage: check_variants_vs_oracle.py <config | S,T,K> <boards> [variant,variant,...]
+# TS_SHOW_DIFF=1: print the first wrong tiles / floats;  TS_WS_ANALYZE=1: the wrong-slide statistics of round 3 (8x8 only)
+
+
+def _dest(p, blk, d):
+    """slide destination of a lone tile on an 8x8 board (cell ids, python ints) and its lane / side masks"""
+    r, c = divmod(p, 8)
+    lane = (0x0101010101010101 << c) if d < 2 else (0xff << (8 * r))
+    below, st = (1 << p) - 1, (8 if d < 2 else 1)
+    side = lane & (below if d in (0, 2) else ~(below | (1 << p)) & (2**64 - 1))
+    bb = blk & side
+    if d in (0, 2):
+        return (bb.bit_length() - 1 + st) if bb else (c if d < 2 else 8 * r)
+    return ((bb & -bb).bit_length() - 1 - st) if bb else (56 + c if d < 2 else 8 * r + 7)
+
+
+def _slide_with_lane(p, occ, blk, d, lane):
+    """ts_core.h slide_cell with the lane mask given (the hypothesis under test supplies a wrong one)"""
+    r, c = divmod(p, 8)
+    st, neg = (8 if d < 2 else 1), d in (0, 2)
+    below = (1 << p) - 1
+    side = lane & (below if neg else ~(below | (1 << p)) & (2**64 - 1))
+    bb = blk & side
+    if neg:
+        dest = (bb.bit_length() - 1 + st) if bb else (c if d < 2 else 8 * r)
+        span = side & ~((1 << dest) - 1)
+    else:
+        dest = ((bb & -bb).bit_length() - 1 - st) if bb else (56 + c if d < 2 else 8 * r + 7)
+        span = side & ((2 << dest) - 1)
+    ahead = bin(occ & span).count("1")
+    return dest + st * ahead if neg else dest - st * ahead
+
+
+def wrong_slide_stats(name, init, blk, act, got, want):
+    """Which tiles are wrong, where, and do they follow from a STALE lane mask (the span mask the previous tile's
+    iteration left in the same register pair)?"""
+    badb = np.flatnonzero((got != want).any(axis=0))
+    if not len(badb):
+        print(f"{name}: wrong-slide statistics: no wrong positions", flush=True)
+        return
+    waves, tiles_per_wave, horiz, match_a, match_below, total = {}, {}, 0, 0, 0, 0
+    multi = 0
+    for b in badb.tolist():
+        ts_ = np.flatnonzero(got[:, b] != want[:, b]).tolist()
+        multi += len(ts_) > 1
+        d = int(act[b])
+        waves.setdefault(b // 64, []).append(b % 64)
+        tiles_per_wave.setdefault(b // 64, set()).update(ts_)
+        horiz += d >= 2
+        bl = int(blk[0, b]) | (int(blk[1, b]) << 32)
+        cells = [int(x) for x in init[:, b]]
+        occ = 0
+        for x in cells:
+            occ |= 1 << x
+        t = ts_[0]  # the first wrong tile: later ones may be consequences (the observation only; positions are independent)
+        total += 1
+        if t > 0:
+            dp = _dest(cells[t - 1], bl, d)
+            stale = ((2 << dp) - 1) if d in (1, 3) else ((2**64 - 1) << dp) & (2**64 - 1)
+            match_a += _slide_with_lane(cells[t], occ, bl, d, stale) == int(got[t, b])
+        match_below += _slide_with_lane(cells[t], occ, bl, d, (1 << cells[t]) - 1) == int(got[t, b])
+    one_index = sum(1 for w in tiles_per_wave.values() if len(w) == 1)
+    hist = np.bincount([t for w in tiles_per_wave.values() for t in w], minlength=init.shape[0])
+    print(f"{name}: wrong-slide statistics over {len(badb)} wrong boards in {len(waves)} waves "
+          f"(of {got.shape[1] // 64}; first wave {min(waves)}, last {max(waves)}):", flush=True)
+    print(f"    horizontal moves: {horiz} of {len(badb)};  boards with more than one wrong tile: {multi}", flush=True)
+    print(f"    waves whose wrong boards all share ONE tile index: {one_index} of {len(waves)};  tile-index histogram over waves: {hist.tolist()}", flush=True)
+    print(f"    wrong result == slide with the PREVIOUS tile's span mask as lane mask (stale v[20:21]): {match_a} of {total}", flush=True)
+    print(f"    wrong result == slide with lane mask (1 << p) - 1 (the register's NEXT value): {match_below} of {total}", flush=True)
+    lanes_per_wave = np.array([len(v) for v in waves.values()])
+    print(f"    wrong lanes per affected wave: min {lanes_per_wave.min()} median {int(np.median(lanes_per_wave))} max {lanes_per_wave.max()}", flush=True)
+    wv = np.array(sorted(waves))
+    print(f"    affected waves by wave-in-block: {np.bincount(wv % 4, minlength=4).tolist()};  by block mod 8: {np.bincount((wv // 4) % 8, minlength=8).tolist()}", flush=True)
+
 cfgname, n = sys.argv[1], int(sys.argv[2])
 only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 if "," in cfgname:
@@ -48,6 +121,16 @@ for name in json.load(open(os.path.join(VDIR, "manifest.json"))):
         obs = env._obs.cpu().numpy()
         bad = np.flatnonzero((obs != wants[i]["obs"]).reshape(n, -1).any(axis=1))
         badf = np.flatnonzero(env._flags.cpu().numpy() != wants[i]["flags"])
+        if i == 0 and os.environ.get("TS_WS_ANALYZE") and cfg["size"] == 8:
+            ref0 = orc.OracleBatch(8, True, 2**30, blk, init, tgt)
+            ref0.reset()
+            ref0.step(acts[0], mode=orc.MODE_AUTORESET)
+            wrong_slide_stats(name, init, blk, acts[0], env._pos.cpu().numpy(), ref0.pos)
+            if os.environ.get("TS_WS_DUMP"):  # raw material for offline hypothesis tests: the wrong boards of this variant
+                gotp = env._pos.cpu().numpy()
+                wb = np.flatnonzero((gotp != ref0.pos).any(axis=0))
+                np.savez_compressed(os.path.join(os.environ["TS_WS_DUMP"], f"ws_dump_{name}.npz"), boards=wb, blk=blk[:, wb], init=init[:, wb],
+                                    act=acts[0][wb], got=gotp[:, wb], want=ref0.pos[:, wb])
         if i == 0 and os.environ.get("TS_SHOW_DIFF"):
             ref0 = orc.OracleBatch(cfg["size"], True, 2**30, blk, init, tgt)
             ref0.reset()

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Development tool: variants of one kernel at the ISA level (no recompilation, so register allocation and
+scheduling stay exactly those of the build under study).
+
+    python tools/isa_patch.py wrong_slide      # round 3: the wrong-slide study (profiles/r03_wrong_slide_isa.md)
+
+Pipeline (what hipcc does, with a text edit in the middle):
+    hipcc -S --cuda-device-only            -> device assembly of the whole translation unit
+    <edit the text of one kernel>
+    clang -x assembler (amdgcn, gfx950)    -> object;   lld -> code object;   clang-offload-bundler -> .hipfb
+    hipcc --cuda-host-only -fcuda-include-gpubinary .hipfb -shared  -> a drop-in libtiler_slider_hip.so variant
+Variants land in build/variants/ with a manifest entry, where tools/check_variants_vs_oracle.py picks them up.
+"""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+VDIR = os.path.join(ROOT, "build", "variants")
+
+
+def run(cmd, **kw):
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    if res.returncode:
+        raise SystemExit(f"{' '.join(cmd)}\n{res.stdout}")
+    return res.stdout
+
+
+def device_asm(src, out, opt="-O3", include=(), defines=()):
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", opt, "-std=c++17", "-S", "--cuda-device-only", *[f"-I{i}" for i in include],
+             *[f"-D{d}" for d in defines], "-o", out, src])
+    return open(out).read()
+
+
+def kernel_span(asm, symbol):
+    """[start, end) of the kernel's instructions in the assembly text (label line to its s_endpgm / .Lfunc_end)."""
+    start = asm.index(f"\n{symbol}:") + 1
+    end = asm.index(".Lfunc_end", start)
+    return start, end
+
+
+def build_variant(name, asm, src, note, opt="-O3", include=(), defines=()):
+    os.makedirs(VDIR, exist_ok=True)
+    base = os.path.join(VDIR, name)
+    open(base + ".s", "w").write(asm)
+    run([f"{LLVM}/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", base + ".s", "-o", base + ".o"])
+    run([f"{LLVM}/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", base + ".hsaco", base + ".o"])
+    run([f"{LLVM}/clang-offload-bundler", "-type=o", "-bundle-align=4096",
+         "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={base}.hsaco",
+         f"-output={base}.hipfb"])
+    run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", base + ".hipfb",
+         opt, "-std=c++17", "-shared", "-fPIC", *[f"-I{i}" for i in include], *[f"-D{d}" for d in defines], "-o", base + ".so", src])
+    for ext in (".o", ".hsaco", ".hipfb"):
+        os.remove(base + ext)
+    mpath = os.path.join(VDIR, "manifest.json")
+    manifest = json.load(open(mpath)) if os.path.exists(mpath) else {}
+    manifest[name] = [note]
+    json.dump(manifest, open(mpath, "w"), indent=1)
+    print(f"built {name}: {note}")
+
+
+def patch_kernel(asm, symbol, edits):
+    """edits: list of (anchor line (stripped) inside the kernel, occurrence index, 'before' | 'after' | 'replace', text)."""
+    a, b = kernel_span(asm, symbol)
+    lines = asm[a:b].split("\n")
+    for anchor, occ, how, text in edits:
+        idx = [i for i, l in enumerate(lines) if l.strip() == anchor]
+        if len(idx) <= occ:
+            raise SystemExit(f"anchor {anchor!r} occurrence {occ} not found in {symbol} ({len(idx)} matches)")
+        i = idx[occ]
+        new = ["\t" + t for t in text.split("\n")]
+        if how == "before":
+            lines[i:i] = new
+        elif how == "after":
+            lines[i + 1:i + 1] = new
+        else:
+            lines[i:i + 1] = new
+    return asm[:a] + "\n".join(lines) + asm[b:]
+
+
+def wrong_slide():
+    """The failing compiled form: the source of commit 0690d71 (parent of round 1's 'fix'), kernel
+    k_small<8, 0, false> at -O3, whose slide loop puts a wrong lane mask into v[20:21] for the horizontally
+    moving lanes of a wave in one iteration (profiles/r02_lds_corruption_bisect.log)."""
+    wdir = os.path.join(ROOT, "build", "wrong_slide")
+    os.makedirs(os.path.join(wdir, "inc"), exist_ok=True)
+    for path, dst in (("tiler_slider_amd/csrc/ts_kernels.hip", "old.hip"), ("tiler_slider_amd/csrc/ts_core.h", "ts_core.h"),
+                      ("include/tiler_slider.h", "inc/tiler_slider.h")):
+        text = run(["git", "-C", ROOT, "show", f"0690d71:{path}"])
+        if dst == "old.hip":
+            text = text.replace('"../../include/tiler_slider.h"', '"inc/tiler_slider.h"')
+        open(os.path.join(wdir, dst), "w").write(text)
+    src = os.path.join(wdir, "old.hip")
+    asm = device_asm(src, os.path.join(wdir, "old_O3.s"), include=(wdir,))
+    sym = "_ZN12_GLOBAL__N_17k_smallILi8ELi0ELb0EEEvNS_5KArgsE"
+    row = "v_lshlrev_b64 v[20:21], v31, s[54:55]"
+    col = "v_lshlrev_b64 v[18:19], v30, s[38:39]"
+    variants = {
+        "ws_ctrl": ("unpatched assembly through the same pipeline (control)", []),
+        "ws_nop_after_row": ("s_nop 7 between the row-mask shift and its first reader", [(row, 0, "after", "s_nop 7")]),
+        "ws_nop_before_shifts": ("s_nop 7 between s_mov_b32 s39, s38 and the two 64-bit shifts", [(col, 0, "before", "s_nop 7")]),
+        "ws_nop_between_shifts": ("s_nop 7 between the column-mask and the row-mask shift", [(row, 0, "before", "s_nop 7")]),
+        "ws_row_from_vgpr": ("row mask shifted from a VGPR pair instead of s[54:55] (no SGPR operand in that 64-bit shift)",
+                             [(row, 0, "replace", "v_mov_b32_e32 v20, 0xff\nv_mov_b32_e32 v21, 0\nv_lshlrev_b64 v[20:21], v31, v[20:21]")]),
+        "ws_both_from_vgpr": ("both lane masks shifted from VGPR pairs (no SGPR operand in either 64-bit shift)",
+                              [(row, 0, "replace", "v_mov_b32_e32 v20, 0xff\nv_mov_b32_e32 v21, 0\nv_lshlrev_b64 v[20:21], v31, v[20:21]"),
+                               (col, 0, "replace", "v_mov_b32_e32 v18, s38\nv_mov_b32_e32 v19, s38\nv_lshlrev_b64 v[18:19], v30, v[18:19]")]),
+        "ws_row_32bit": ("row mask built with 32-bit shifts only (0xff << (r*8 & 31) into the low or the high word)",
+                         [(row, 0, "replace", "v_and_b32_e32 v20, 24, v31\nv_mov_b32_e32 v21, 0xff\nv_lshlrev_b32_e32 v20, v20, v21\n"
+                                              "v_cmp_gt_u32_e64 s[60:61], 32, v31\ns_nop 1\nv_cndmask_b32_e64 v21, v20, 0, s[60:61]\n"
+                                              "v_cndmask_b32_e64 v20, 0, v20, s[60:61]")]),
+        "ws_wait_stores": ("s_waitcnt vmcnt(0) at the top of every slide iteration (no position store in flight)",
+                           [("ds_read_u8 v16, v27", 0, "before", "s_waitcnt vmcnt(0)")]),
+        "ws_nop_after_exec": ("s_nop 7 behind the s_and_saveexec / branch that opens the slide body",
+                              [("v_and_b32_e32 v31, 0xf8, v16", 0, "before", "s_nop 7")]),
+    }
+    only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+    for name, (note, edits) in variants.items():
+        if only and name not in only:
+            continue
+        build_variant(name, patch_kernel(asm, sym, edits), src, f"0690d71 -O3, k_small<8,0,false>: {note}", include=(wdir,))
+    # the same source compiled at -O1 (clean in round 2) as a second control
+    if not only or "ws_O1" in only:
+        asm1 = device_asm(src, os.path.join(wdir, "old_O1.s"), opt="-O1", include=(wdir,))
+        build_variant("ws_O1", asm1, src, "0690d71 -O1 (clean in round 2), through the same pipeline", opt="-O1", include=(wdir,))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 2 or sys.argv[1] != "wrong_slide":
+        raise SystemExit(__doc__)
+    wrong_slide()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development tool: every kernel family at a batch just beyond the Infinity Cache (where the out-of-cache launch
 policies apply: nontemporal stores, one-wave blocks, bounded residency, half waves), against the oracle: reset + 3 steps,
-plain and with the optional outputs.  Usage: python tools/ooc_fuzz.py"""
+plain and with the optional outputs; then an `onehot` leg — the fused step + one-hot + reward launch (cfg2's kernel) with
+~300 MB of planes per step, plane for plane against the oracle.  Usage: python tools/ooc_fuzz.py [--onehot-only]"""
 import os
 import sys
 import time
@@ -26,7 +27,7 @@ for S, T in ((9, 4), (10, 17), (12, 8), (15, 32), (16, 40), (17, 3), (20, 33), (
     cases.append((S, T, S))
 bad = 0
 t0 = time.time()
-for S, T, K in cases:
+for S, T, K in ([] if "--onehot-only" in sys.argv else cases):
     C = S * S
     n = (300_000_000 // (12 * C)) + int(rng.integers(1, 200))  # ~300 MB of observation: nontemporal path, ragged N
     mc = bool(rng.integers(0, 2))
@@ -51,5 +52,30 @@ for S, T, K in cases:
         bad += not ok
         print(f"S={S:2d} T={T:3d} K={K:2d} mc={int(mc)} N={n:9d} extras={int(extras)}: {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
         del env, ref
+# one-hot leg: batch sized by the PLANES (Ch * C floats per board), so that the one-hot stream is the out-of-cache one
+for S, T, K in cases:
+    C = S * S
+    mc = bool(rng.integers(0, 2))
+    Ch = 1 + 2 * T if mc else 3
+    n = (300_000_000 // (4 * C * Ch)) + int(rng.integers(1, 200))
+    if K + 2 * T <= C:
+        blk, init, tgt = orc.generate(S, T, T, K, n, seed=300 + S * 31 + T)
+    else:
+        blk, init, _ = orc.generate(S, T, 0, K, n, seed=300 + S * 31 + T)
+        _, _, tgt = orc.generate(S, 0, T, 0, n, seed=400 + S * 31 + T)
+    ref = orc.OracleBatch(S, mc, 5, blk, init, tgt)
+    env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=5, auto_reset=True,
+                                        with_reward=True, with_onehot=True)
+    ok = np.array_equal(env.reset().cpu().numpy(), ref.reset())
+    for i in range(3):
+        a = orc.fill_actions(n, seed=10, step_index=i)
+        obs, done, info = env.step(torch.from_numpy(a))
+        w = ref.step(a, mode=orc.MODE_AUTORESET, reward=True, onehot=True)
+        ok &= np.array_equal(obs.cpu().numpy(), w["obs"]) and np.array_equal(info["flags"].cpu().numpy(), w["flags"])
+        ok &= np.array_equal(info["reward"].cpu().numpy(), w["reward"]) and np.array_equal(info["onehot"].cpu().numpy(), w["onehot"])
+        del w
+    bad += not ok
+    print(f"S={S:2d} T={T:3d} K={K:2d} mc={int(mc)} N={n:9d} onehot Ch={Ch:3d}: {'ok' if ok else 'MISMATCH'}  [{time.time() - t0:.0f} s]", flush=True)
+    del env, ref
 print("ooc fuzz:", "OK" if bad == 0 else f"{bad} MISMATCHES")
 sys.exit(0 if bad == 0 else 1)
