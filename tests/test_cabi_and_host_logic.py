@@ -253,3 +253,29 @@ def test_level_records_keep_the_reference_names():
     assert env.multi_color is True and env.size == 4
     with pytest.raises(NotImplementedError):
         ImageLoader.parse_puzzle_image(np.zeros((10, 10, 3)), False)
+
+
+def test_no_64bit_read_of_the_last_allocated_vgpr():
+    """gfx950: a 64-bit shift whose shift amount sits in the LAST register of the wave's VGPR allocation occasionally
+    reads v0 instead (profiles/r03_wrong_slide_isa.md).  The build pads such allocations; the scanner checks the
+    shipped code object instruction by instruction."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scan_last_vgpr
+    from tiler_slider_amd import _cabi
+    class_a, class_b, n_kernels = scan_last_vgpr.scan(_cabi.LIB_PATH)
+    assert n_kernels > 300  # the metadata was found and parsed
+    assert class_a == [] and class_b == []
+
+
+def test_vgpr_allocation_padding_rule():
+    asm = "\n".join([
+        "\t.amdhsa_kernel k_full", "\t\t.amdhsa_next_free_vgpr 48", "\t\t.amdhsa_accum_offset 48", "\t.end_amdhsa_kernel",
+        "\t.amdhsa_kernel k_slack", "\t\t.amdhsa_next_free_vgpr 33", "\t.end_amdhsa_kernel",
+        "amdhsa.kernels:", "  - .agpr_count:     0", "    .name:           k_full", "    .vgpr_count:     48",
+        "  - .agpr_count:     0", "    .name:           k_slack", "    .vgpr_count:     33"])
+    from tiler_slider_amd import _cabi
+    out, n = _cabi.pad_vgpr_allocations(asm)
+    assert n == 1
+    assert ".amdhsa_next_free_vgpr 49" in out and ".amdhsa_next_free_vgpr 33" in out and ".amdhsa_accum_offset 48" in out
+    assert re.search(r"\.name:\s+k_full\n\s+\.vgpr_count:\s+49", out) and re.search(r"\.name:\s+k_slack\n\s+\.vgpr_count:\s+33", out)

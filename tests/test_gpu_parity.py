@@ -435,6 +435,11 @@ LARGE_BATCH_SHAPES = [
     (7, 9, 8, False, 150_000), (8, 2, 12, True, 150_000), (8, 20, 10, True, 150_000), (8, 26, 10, False, 100_000),
     (9, 4, 9, True, 100_000), (12, 16, 20, False, 60_000), (16, 40, 30, True, 40_000), (20, 6, 30, True, 30_000),
     (32, 64, 100, False, 12_000),
+    # 8x8 with five tiles, plain outputs, cache-resident: in the round-2 build this kernel (k_small<8, 5, false, false>) slid
+    # tiles past their row in 2-7 % of the boards - its row-mask shift read the last VGPR of the allocation
+    # (profiles/r03_wrong_slide_isa.md); found by tools/scan_last_vgpr.py, not by a test: the shape was not covered at scale
+    (8, 5, 10, True, 300_000), (8, 5, 10, False, 300_000), (7, 5, 8, True, 300_000), (6, 7, 4, True, 250_000), (8, 3, 10, True, 300_000),
+    (8, 1, 10, False, 300_000), (8, 4, 6, True, 300_000), (8, 6, 6, False, 300_000), (8, 7, 6, True, 300_000), (7, 3, 5, False, 300_000),
 ]
 
 

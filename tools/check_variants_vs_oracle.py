@@ -43,7 +43,7 @@ def _slide_with_lane(p, occ, blk, d, lane):
         span = side & ~((1 << dest) - 1)
     else:
         dest = ((bb & -bb).bit_length() - 1 - st) if bb else (56 + c if d < 2 else 8 * r + 7)
-        span = side & ((2 << dest) - 1)
+        span = side & (((2 << dest) - 1) if dest >= 0 else 0)  # a wrong lane mask can put an "obstacle" in front of the board
     ahead = bin(occ & span).count("1")
     return dest + st * ahead if neg else dest - st * ahead
 
@@ -80,7 +80,7 @@ def wrong_slide_stats(name, init, blk, act, got, want):
     hist = np.bincount([t for w in tiles_per_wave.values() for t in w], minlength=init.shape[0])
     print(f"{name}: wrong-slide statistics over {len(badb)} wrong boards in {len(waves)} waves "
           f"(of {got.shape[1] // 64}; first wave {min(waves)}, last {max(waves)}):", flush=True)
-    print(f"    horizontal moves: {horiz} of {len(badb)};  boards with more than one wrong tile: {multi}", flush=True)
+    print(f"    horizontal moves: {horiz} of {len(badb)} (vertical: {len(badb) - horiz});  boards with more than one wrong tile: {multi}", flush=True)
     print(f"    waves whose wrong boards all share ONE tile index: {one_index} of {len(waves)};  tile-index histogram over waves: {hist.tolist()}", flush=True)
     print(f"    wrong result == slide with the PREVIOUS tile's span mask as lane mask (stale v[20:21]): {match_a} of {total}", flush=True)
     print(f"    wrong result == slide with lane mask (1 << p) - 1 (the register's NEXT value): {match_below} of {total}", flush=True)
