@@ -172,10 +172,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--placement-trials", type=int, default=6,
-                    help="VecTilerSliderEnv(placement_trials=...): candidate allocations of the output buffers rated at "
-                         "construction for batches beyond the Infinity Cache (1 = take the first; reported in config)")
+                    help="VecTilerSliderEnv(placement_trials=...) for batches beyond the Infinity Cache: 0 = the library's static "
+                         "launch policy, 1 = launch policy rated at construction on the first allocation (the class default), "
+                         "k > 1 = also up to k candidate allocations of the output buffers (reported in config)")
+    ap.add_argument("--policy", default=None,
+                    help="launch_hint,emit_edges,lines_lanes: fix the per-call launch policy of ts_dims (use with --placement-trials 0 "
+                         "to profile exactly the launches a tuned run settled on)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-halves-on-two-streams figure")
     ap.add_argument("--no-sibling", action="store_true", help="skip the out-of-cache sibling of a cache-resident config")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short timings of the other single-GPU BASELINE configs (cfg2, cfg4) that a cfg1 run appends")
     ap.add_argument("--compact-u8", action="store_true",
                     help="also time the opt-in uint8-observation variant (reported as compact_u8_obs; off by "
                          "default so that a profile of the default run contains only the headline launches)")
@@ -217,6 +223,8 @@ def main():
                                    seed=LEVEL_SEED, multi_color=True, max_steps=2**30, board_offset=rank * n,
                                    device=device, auto_reset=True, with_reward=cfg["reward"],
                                    with_onehot=cfg["onehot"], placement_trials=args.placement_trials)
+    if args.policy:
+        env._dims.launch_hint, env._dims.emit_edges, env._dims.lines_lanes = (int(x) for x in args.policy.split(","))
     env.reset()
     ring = []
     L = _cabi.lib()
@@ -333,6 +341,17 @@ def main():
         del big, acts
         torch.cuda.empty_cache()
 
+    # The other single-GPU configs of BASELINE.json (cfg2: 5x5 + one-hot + reward; cfg4: 15x15 / 32 tiles - the genuinely
+    # HBM-bound ones), a few hundred ms each, so that the driver's one default run records all three: with the library's static
+    # launch policy (placement_trials = 0), with the class default (launch policy rated at construction on the first
+    # allocation) and with the construction-time choice among candidate buffers (the headline's own --placement-trials).
+    others = None
+    if world == 1 and args.config == "cfg1" and not args.boards and not args.no_other_configs:
+        others = {}
+        for name in ("cfg2", "cfg4"):
+            others[name] = time_config(name, args.placement_trials, min(args.steps, 100), device, L, stream)
+            torch.cuda.empty_cache()
+
     # two halves of the batch on two streams (tiler_slider_amd.pipelined): what a double-buffered actor loop gets when
     # one half steps while it works on the other - the ramps of consecutive launches overlap.  Not the headline: the
     # synchronous step() of the reference API joins all boards every step.
@@ -395,6 +414,8 @@ def main():
                        # construction-time choice among candidate allocations of the output buffers (outside the
                        # timed region; only for batches beyond the Infinity Cache): VecTilerSliderEnv docstring
                        "placement_trials": args.placement_trials, "placement": env.placement_report,
+                       "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges,
+                                         "lines_lanes": env._dims.lines_lanes},
                        "parallelism": f"boards sharded over {world} GPU(s), no data-path collective",
                        "level_seed": hex(LEVEL_SEED), "action_seed": hex(ACTION_SEED)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -418,6 +439,8 @@ def main():
                                                   "profiles/traffic_pmc.json" % rec["fetch_bytes_raw"])
         if sibling is not None:
             line["roofline"]["hbm_sibling"] = sibling
+        if others is not None:
+            line["other_configs"] = others
         if api is not None:
             line["python_step_api"] = api
         if pipelined is not None:
@@ -436,6 +459,51 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def time_config(name, trials, steps, device, L, stream):
+    """Kernel time (HIP events on the launch stream) of one BASELINE config, first allocation and tuned."""
+    import torch
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    cfg = CONFIGS[name]
+    n = cfg["boards"]
+    bps = algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
+    acts = []
+    for i in range(4):
+        a = torch.empty(n, dtype=torch.uint8, device=device)
+        _cabi.check(L.ts_fill_actions(n, ACTION_SEED, 0, i, a.data_ptr(), stream), "ts_fill_actions")
+        acts.append(a)
+    out = {"workload": f"{name}: {n:,} concurrent {cfg['size']}x{cfg['size']} boards, T={cfg['tiles']}, K={cfg['obstacles']}, multi_color"
+                       + (", + one-hot + Manhattan reward" if cfg["onehot"] else ""),
+           "kernel": dominant_kernel(cfg, n, L), "algorithmic_bytes_per_board_step": bps, "algorithmic_bytes_per_launch": bps * n,
+           "steps": steps}
+    for key, k in (("library_policy", 0), ("first_allocation", 1), ("tuned", trials)):
+        if key == "tuned" and trials <= 1:
+            break
+        env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"], seed=LEVEL_SEED,
+                                       multi_color=True, max_steps=2**30, device=device, auto_reset=True, with_reward=cfg["reward"],
+                                       with_onehot=cfg["onehot"], placement_trials=k)
+        env.reset()
+        for i in range(10):
+            env.step_async(acts[i & 3])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            env.step_async(acts[i & 3])
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / steps
+        gbs = bps * n / us / 1e3
+        out[key] = {"placement_trials": k, "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s", "achieved": gbs,
+                    "achieved_unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS,
+                    "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges, "lines_lanes": env._dims.lines_lanes},
+                    "placement": env.placement_report}
+        del env
+        torch.cuda.empty_cache()
+    rec = pmc_traffic(name, n)
+    if rec is not None:
+        out["traffic"] = rec["write_bytes"] + rec["fetch_bytes_x2"]
+    return out
 
 
 def time_gathers(env, ring, world, n, dist, torch, device, steps):

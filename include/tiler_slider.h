@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 3
+#define TS_ABI_VERSION 4
 #define TS_MAX_SIZE 32   /* cell ids: uint8 up to 16x16, uint16 up to 32x32 (ts_cell_bytes) */
 #define TS_MAX_TILES 255 /* observation stores tile index + 1 in one byte */
 
@@ -99,11 +99,15 @@ typedef struct ts_dims {
   int32_t n_targets;   /* Tt, 0..TS_MAX_TILES        (len(target_locations)) */
   int32_t multi_color; /* 0 / 1                      (GameState.multi_color) */
   int32_t max_steps;   /* >= 1                       (TilerSliderEnv.max_steps) */
-  int32_t launch_hint; /* 0 = the library's launch policy.  -3 .. +3: resident blocks per CU of launches whose
-                        * outputs do not fit the Infinity Cache, relative to that policy - speed only, never
-                        * results; the best value depends on where the output buffers were allocated
-                        * (VecTilerSliderEnv(placement_trials=k) finds it).
-                        * Anything else: TS_ERR_DIMS.  (The field was `reserved`, must-be-zero, before.) */
+  /* Launch policy of THIS call (speed only, never results; 0 everywhere = the library's own policy).  They matter for
+   * launches whose outputs do not fit the 256 MiB Infinity Cache, where the best values depend on the shape and on where
+   * the output buffers were allocated; VecTilerSliderEnv rates a few combinations at construction. */
+  int32_t launch_hint; /* -8 .. +8: resident blocks per CU relative to the policy.  Anything else: TS_ERR_DIMS.
+                        * (The field was `reserved`, must-be-zero, before ABI v3.) */
+  int32_t emit_edges;  /* ABI v4.  0 = policy; 1 + e (e = 0 .. 3): bit 0 / bit 1 of e = the first / last store instruction
+                        * of every wave's chunk of observation is a write-back store instead of a nontemporal one. */
+  int32_t lines_lanes; /* ABI v4.  0 = policy; 4 / 8 / 16 = lanes per board of the kernel for boards above 8x8, where
+                        * that form exists for the shape (else the policy's choice is taken). */
 } ts_dims;
 
 typedef struct ts_state {
@@ -229,10 +233,22 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
  *       blocks, bounded residency, half waves (different instantiations of the same kernels).  Default
  *       268435456 (the 256 MiB Infinity Cache of MI355X); 0 = every launch takes the out-of-cache kernels
  *       (the parity tests use this to cover them at small batch sizes).
+ *   TS_TUNE_LINES_LANES  lanes per board of the kernel for boards above 8x8: 0 (default) = by tile count
+ *       (4 lanes up to 4 tiles on boards up to 16x16, 8 lanes up to 16 tiles, else 16); 4 / 8 / 16 = forced
+ *       where that form exists (at most two tiles per lane with 4 and 8 lanes; 8 lanes at least above 16x16).
+ *   TS_TUNE_LINES_BPW  boards per wave of that kernel: 0 (default) = the policy (64 / lanes per board, fewer for
+ *       boards whose observation is large: a wave's contiguous chunk of output should stay near 10 KB);
+ *       1 .. 64 / lanes = forced (the remaining lanes idle).
+ *   TS_TUNE_EMIT_EDGES  launches beyond the Infinity Cache: bit 0 / bit 1 = the first / last store instruction of
+ *       every wave's chunk of observation goes out as a write-back store instead of a nontemporal one; 4 (default) =
+ *       the library's policy per kernel and shape.
  * value >= 0 sets the knob, value < 0 only queries.  Returns the value before the call, or
  * -1 for an unknown key.  Thread-safe (one atomic per knob). */
 #define TS_TUNE_MULTI_MIN_BOARDS 0
 #define TS_TUNE_NT_THRESHOLD_BYTES 1
+#define TS_TUNE_LINES_LANES 2
+#define TS_TUNE_LINES_BPW 3
+#define TS_TUNE_EMIT_EDGES 4
 int64_t ts_tuning(int32_t key, int64_t value);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */

@@ -472,6 +472,50 @@ def test_large_batches_vs_oracle(torch_cuda, oracle, S, T, K, mc, N):
         assert np.array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
 
 
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+@pytest.mark.parametrize("S,T,Tt,K,mc,N", [(9, 4, 4, 9, True, 1031), (12, 8, 8, 16, False, 517), (16, 3, 3, 30, True, 259), (20, 6, 6, 30, False, 131),
+                                           (32, 2, 2, 100, True, 37), (15, 2, 1, 24, True, 300), (13, 1, 3, 30, False, 222), (11, 7, 7, 5, False, 401),
+                                           (10, 5, 8, 3, True, 333), (24, 16, 16, 60, True, 67)])
+def test_lines_kernel_lanes_per_board_forced(torch_cuda, oracle, lanes, S, T, Tt, K, mc, N):
+    """k_lines deals a board's lines and tiles over 4, 8 or 16 lanes (the policy picks by tile count): every form that
+    exists for a shape must give the oracle's outputs, optional outputs included, cache-resident and out-of-cache kernels."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    L = _cabi.lib()
+    blk, init, _ = oracle.generate(S, T, 0, K, N, seed=700 + S + T)
+    _, _, tgt = oracle.generate(S, 0, Tt, 0, N, seed=800 + S + Tt)
+    if Tt >= 2:
+        tgt[1, 3::11] = tgt[0, 3::11]  # duplicate targets: the "highest index wins" fix-up
+    before = L.ts_tuning(_cabi.TUNE_LINES_LANES, lanes)
+    nt_before = L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, -1)
+    try:
+        for nt in (nt_before, 0):
+            L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, nt)
+            ref = oracle.OracleBatch(S, mc, 7, blk, init, tgt)
+            env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True, with_reward=True,
+                                                with_onehot=True, with_valid_moves=True)
+            plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True)
+            want0 = ref.reset()
+            np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
+            np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
+            for step in range(10):
+                act = oracle.fill_actions(N, seed=31 + S, step_index=step)
+                obs, done, info = env.step(torch.from_numpy(act))
+                want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True, onehot=True, valid=True)
+                ctx = f"lanes={lanes} nt={nt} S={S} T={T} step={step}"
+                _assert_plain_step(plain, torch.from_numpy(act), ref, want, ctx)
+                np.testing.assert_array_equal(env.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64), err_msg=ctx)
+                np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+                np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"], err_msg=ctx)
+                np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
+                np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
+                np.testing.assert_array_equal(env._valid.cpu().numpy(), want["valid"], err_msg=ctx)
+            np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
+    finally:
+        L.ts_tuning(_cabi.TUNE_LINES_LANES, before)
+        L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, nt_before)
+
+
 def test_onehot_per_float_fallback_at_scale(torch_cuda, oracle):
     """8x8 with 30 tiles in multi-colour mode has 61 planes: four boards' one-hot byte image is
     above the 16 KiB LDS budget, so k_small evaluates every output float from the staged cells."""
@@ -808,15 +852,21 @@ def test_placement_trials_leave_no_trace(torch_cuda, oracle):
     from tiler_slider_amd import VecTilerSliderEnv
     small = VecTilerSliderEnv.random(1000, size=4, num_tiles=2, num_obstacles=2, seed=3, placement_trials=4)
     assert "skipped" in small.placement_report
-    N = 1 << 20  # 5x5: 315 MB of observation per step, beyond the Infinity Cache
-    kw = dict(size=5, num_tiles=2, num_obstacles=3, seed=11, multi_color=True, max_steps=7, with_reward=True)
-    for autoreset in (False, True):
-        plain = VecTilerSliderEnv.random(N, auto_reset=autoreset, **kw)
+    # 5x5 at 1M boards: 315 MB of observation per step, beyond the Infinity Cache; 9x9 at 300k boards: the same for the kernel of
+    # large boards, whose search also tries the lanes per board
+    for N, kw, autoreset in ((1 << 20, dict(size=5, num_tiles=2, num_obstacles=3, seed=11, multi_color=True, max_steps=7, with_reward=True), False),
+                             (1 << 20, dict(size=5, num_tiles=2, num_obstacles=3, seed=11, multi_color=True, max_steps=7, with_reward=True), True),
+                             (300_000, dict(size=9, num_tiles=4, num_obstacles=9, seed=12, multi_color=False, max_steps=7, with_reward=True), True)):
+        plain = VecTilerSliderEnv.random(N, auto_reset=autoreset, placement_trials=0, **kw)
+        assert plain.placement_report is None and (plain._dims.launch_hint, plain._dims.emit_edges, plain._dims.lines_lanes) == (0, 0, 0)
         tuned = VecTilerSliderEnv.random(N, auto_reset=autoreset, placement_trials=3, obs_buffers=2, **kw)
         rep = tuned.placement_report
+        pol = rep["policy"][rep["chosen"]]
+        assert (tuned._dims.launch_hint, tuned._dims.emit_edges, tuned._dims.lines_lanes) == (pol["launch_hint"], pol["emit_edges"], pol["lines_lanes"])
+        assert rep["us_per_step"][rep["chosen"]] <= rep["library_policy_us"][rep["chosen"]]
         assert 1 <= rep["trials"] <= 3 and len(rep["us_per_step"]) == rep["trials"] and 0 <= rep["chosen"] < rep["trials"]
         assert rep["us_per_step"][rep["chosen"]] == min(rep["us_per_step"])
-        assert tuned._dims.launch_hint == rep["launch_hint"][rep["chosen"]] and -1 <= tuned._dims.launch_hint <= 1
+        assert tuned._dims.launch_hint == rep["launch_hint"][rep["chosen"]] and -8 <= tuned._dims.launch_hint <= 8
         for t in ("_pos", "_step_count", "_done", "_flags", "_reward"):
             assert torch.equal(getattr(plain, t), getattr(tuned, t)), t
         assert int(tuned._obs.abs().sum()) == 0
@@ -842,7 +892,7 @@ def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, o
     ref = VecTilerSliderEnv.random(N, **kw)
     env = VecTilerSliderEnv.random(N, **kw)
     ref.reset(), env.reset()
-    for step, hint in enumerate((-3, -2, -1, 1, 2, 3)):
+    for step, hint in enumerate((-8, -3, -1, 1, 3, 8)):
         act = torch.from_numpy(oracle.fill_actions(N, seed=21, step_index=step))
         env._dims.launch_hint = hint
         o1, d1, i1 = ref.step(act)
@@ -851,7 +901,7 @@ def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, o
         assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(ref.positions, env.positions), hint
         if onehot:
             assert torch.equal(i1["onehot"], i2["onehot"]), hint
-    env._dims.launch_hint = 4
+    env._dims.launch_hint = 9
     with pytest.raises(Exception):
         env.step(act)
 

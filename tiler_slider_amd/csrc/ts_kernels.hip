@@ -49,6 +49,15 @@
 #ifndef TS_EMIT_PRIO  // s_setprio level while a wave streams its observation out (0 = unchanged)
 #define TS_EMIT_PRIO 0
 #endif
+#ifndef TS_EMIT_ALIGN  // out-of-cache emit loop: store instructions cover whole 128-byte lines (see emit_bytes_as_f32)
+#define TS_EMIT_ALIGN 1
+#endif
+#ifndef TS_EMIT_SHARED  // the pieces of a line that two waves share: 0 = nontemporal like the rest, 1 = plain (write-back), 2 = agent scope
+#define TS_EMIT_SHARED 1
+#endif
+#ifndef TS_EMIT_EDGE_PLAIN  // experiment: first and last store instruction of a chunk as write-back stores
+#define TS_EMIT_EDGE_PLAIN 0
+#endif
 #ifndef TS_ABLATE_DENSE  // store-only ablation writes observation-like data (1 byte in 8 non-zero) instead of near-zeros
 #define TS_ABLATE_DENSE 0
 #endif
@@ -141,6 +150,7 @@ struct KArgs {
   uint32_t oh_boards;   // one-hot byte image: boards per chunk (0 = evaluate per float)
   uint32_t lds_oh_off;  // offset of that image inside the wave's carve
   uint32_t bpw;         // boards per wave (k_small: 64, k_lines: 4; fewer beyond the Infinity Cache)
+  uint32_t emit_edges;  // out-of-cache launches: bit 0 / 1 = first / last store instruction of a wave's chunk as write-back stores
 };
 
 // Orders LDS traffic between the lanes of ONE wave.  The hardware executes a wave's DS
@@ -185,6 +195,15 @@ __device__ __forceinline__ f32x4 bytes_to_f4(uint32_t w) {
 __device__ __forceinline__ void store16_agent_scope(void *dst, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v));
 }
+// 1 = plain (write-back in the XCD's L2), 2 = agent scope; as instructions, so that no optimisation pass can fold them into a
+// neighbouring nontemporal store (with the same wait states behind them as above)
+template <int POLICY>
+__device__ __forceinline__ void store16_policy(void *dst, f32x4 v) {
+  if constexpr (POLICY == 2)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v));
+  else
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v));
+}
 __device__ __forceinline__ void store4_agent_scope(void *dst, uint32_t v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v));
 }
@@ -202,7 +221,7 @@ __device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
 // k_small / k_lines: the cache-resident and the out-of-cache launch are different instantiations,
 // so a profile lists them as different kernels.
 template <bool NT>
-__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane) {
+__device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane, uint32_t edges = 0) {
   const int nf4 = nfl >> 2;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
   f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
@@ -225,8 +244,44 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
     }
 #else
     if constexpr (NT) {
+#if TS_EMIT_ALIGN
+      // Store instructions that cover whole 128-byte lines (round 3, tools/align_probe.*, profiles/r03_align_probe.log).
+      // A wave's chunk starts wherever its first board starts: at 12 * S * S * n0 bytes, a multiple of 128 only for
+      // even board sizes (k_small's 32 / 64 boards per wave always are).  With `dst` m sixteenths of a line past a line
+      // start, lane l of instruction k used to store unit 64 k + l of the chunk: every instruction then began and ended
+      // inside a line, and nontemporal stores of partial lines cost a quarter of the write rate (15x15: 5.3 -> 6.9 TB/s
+      // in the store-only probe) even though the next instruction of the same wave completes the line.  Here instruction k
+      // stores units 64 k + l - m: whole lines, except the first and last line of the chunk, which the neighbouring
+      // waves share; those pieces go out as plain (write-back) stores, so that the two halves meet in the XCD's L2.
+      const int m = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u);
+      const int total = nf4 + m, iters = (total + kWave - 1) >> 6;
+      const int last_line = total >> 3;
+      const bool tail_shared = (total & 7) != 0;
+      auto edge = [&](int k, bool whole) {  // first / last instruction of the chunk: predicated, shared pieces write-back
+        const int u = k * kWave + lane, q = u - m;
+        if (q >= 0 && q < nf4) {
+          const f32x4 v = bytes_to_f4(w[q]);
+          const bool shared = (m != 0 && u < 8) || (tail_shared && (u >> 3) == last_line);
+          // (an asm statement: written as two C++ stores the compiler merges the branches into ONE store and drops the
+          // nontemporal hint of the whole instruction - a third of a 4x4 half wave's stores went out plain, 134 -> 227 us)
+          if ((shared && TS_EMIT_SHARED != 0) || whole)
+            store16_policy<TS_EMIT_SHARED == 2 ? 2 : 1>(&d4[q], v);
+          else
+            __builtin_nontemporal_store(v, &d4[q]);
+        }
+      };
+      // `edges` (KArgs.emit_edges, chosen per launch on the host): bit 0 / bit 1 = the chunk's first / last store instruction
+      // goes out as a write-back store as a whole (see edge_policy)
+      edge(0, (edges & 1u) != 0 || TS_EMIT_EDGE_PLAIN);
+      const uint32_t *wm = w - m;
+      f32x4 *dm = d4 - m;
+#pragma unroll TS_EMIT_UNROLL
+      for (int u = kWave + lane; u < (iters - 1) * kWave; u += kWave) __builtin_nontemporal_store(bytes_to_f4(wm[u]), &dm[u]);
+      if (iters > 1) edge(iters - 1, (edges & 2u) != 0 || TS_EMIT_EDGE_PLAIN);
+#else
 #pragma unroll TS_EMIT_UNROLL
       for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+#endif
     } else {
       // the agent-scope store is an asm statement - a convergent operation to the compiler, which does not unroll a
       // loop around one with a run-time remainder; a hand-unrolled version measured the same (30.2 vs 30.2 us at cfg1)
@@ -364,7 +419,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
 #endif
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
-      emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
+      emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
     }
     return;
   }
@@ -622,7 +677,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
-      if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
+      if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
       if (a.obs_u8) emit_bytes_raw<16, NT>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
     }
   }
@@ -655,7 +710,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < nbc ? (nb - c0) : nbc;
-      emit_bytes_as_f32<NT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane);
+      emit_bytes_as_f32<NT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
     }
   } else if (EXTRAS && a.onehot) {
     // Fallback for very many planes (one board's image above the LDS budget): every output
@@ -931,28 +986,36 @@ __global__ __launch_bounds__(256) void k_multi(const KArgs a) {
 //     flagged boards pay for the "highest index wins" fix-up (state.py:209-211);
 //   * EXTRAS: legality mask by free-neighbour tests, Manhattan reward, one-hot planes.
 // ------------------------------------------------------------------------------------------
-constexpr int kLinesG = 16;                   // lanes per board
-constexpr int kLinesBPW = kWave / kLinesG;    // boards per wave
+constexpr int kLinesG = 16;                   // lanes per board of ts_prepare's mapping (and the default of k_lines)
+constexpr int kLinesBPW = kWave / kLinesG;    // boards per wave with 16 lanes per board
 constexpr int lines_record_words(bool wide) { return wide ? 128 : 32; }
 // Record of one board in ts_state.lines (uint32 words; include/tiler_slider.h):
 //   S <= 16: w[j] = Br[j] | Bc[j] << 16 (j < 16)     w[16 + j] = Tm[j]     bit 31 of w[16]: duplicate targets
 //   S  > 16: w[j] = Br[j], w[32 + j] = Bc[j], w[64 + j] = Tm[j] (j < 32)   bit 0 of w[96]: duplicate targets
 // Br[r] / Bc[c]: obstacles of row r / column c (bit i = i-th cell along the line); Tm[r]: targets of row r.
+//
+// LPB = lanes per board (round 3): 16, 8 or 4.  A board's lines and tiles are dealt over its LPB lanes (lane j owns
+// lines j, j + LPB, ... and tiles j, j + LPB, ...), a wave carries 64 / LPB boards.  Sparse boards - the reference's own
+// large-board tests have 1 .. 5 tiles - left most of 16 lanes idle and gave a wave only 4 boards (3.9 KB of output at 9x9);
+// with 4 lanes per board a wave carries 16 boards, four times the bytes per wave for the same fixed cost (state loads,
+// table loads, LDS set-up, three wave syncs).
 
-template <bool WIDE, int TPL, bool NT, bool EXTRAS>
+template <bool WIDE, int LPB, int TPL, bool NT, bool EXTRAS>
 __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, const int S, const uint32_t invS) {
   using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
-  constexpr int G = kLinesG, BPW = kLinesBPW;
-  constexpr int R = WIDE ? 2 : 1;   // lines per lane
-  constexpr int NL = G * R;         // line slots of one board in LDS
+  constexpr int G = LPB, BPW = kWave / LPB;
+  constexpr int NLN = WIDE ? 32 : 16;  // line slots of one board
+  constexpr int R = NLN / G;           // lines per lane
+  constexpr int W2 = WIDE ? 2 : 1;     // words per line in the obstacle table (row and column masks apart above 16x16)
   constexpr int REC = lines_record_words(WIDE);
+  static_assert(G == 4 || G == 8 || G == 16, "lanes per board");
   auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
   auto mul_s = [&](int x) -> int { return (int)__umul24((uint32_t)x, (uint32_t)S); };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
-  const int g = lane >> 4, j = lane & (G - 1);
-  const int bpw = (int)a.bpw;  // boards per wave: 4, or 2 (the upper lanes idle) — see lines_boards_per_wave
+  const int g = lane / G, j = lane & (G - 1);
+  const int bpw = (int)a.bpw;  // boards per wave: 64 / LPB (or fewer: the upper lanes idle)
   const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform
   const int64_t N = a.N;
@@ -965,29 +1028,30 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   const int C = S * S;
   const int T = a.T, Tt = a.Tt;
   const bool mc = a.mc != 0;
-  const uint64_t gmask = 0xffffull << (g * G);
+  const uint64_t gmask = ((1ull << G) - 1ull) << (g * G);
 
   unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;          // [BPW][3C] bytes, flat
-  uint32_t *lnB = reinterpret_cast<uint32_t *>(img + a.lds_stage_off);  // obstacle line masks [BPW][NL] (x2 when WIDE)
-  uint32_t *occ = lnB + BPW * NL * R;                                   // pre-move tiles along the move's lines
-  uint32_t *nrw = occ + BPW * NL;                                       // post-move tiles by row (set-equality win test, legality mask)
-  uint16_t *tcells = reinterpret_cast<uint16_t *>(nrw + BPW * NL);      // EXTRAS, single-colour reward: target cells [BPW][Tt]
+  uint32_t *lnB = reinterpret_cast<uint32_t *>(img + a.lds_stage_off);  // obstacle line masks [BPW][NLN] (x2 when WIDE)
+  uint32_t *occ = lnB + BPW * NLN * W2;                                 // pre-move tiles along the move's lines
+  uint32_t *nrw = occ + BPW * NLN;                                      // post-move tiles by row (set-equality win test, legality mask)
+  uint16_t *tcells = reinterpret_cast<uint16_t *>(nrw + BPW * NLN);     // EXTRAS, single-colour reward: target cells [BPW][Tt]
   unsigned char *ohimg = img + a.lds_oh_off;                            // EXTRAS, one-hot: one piece of the wave's plane stream
-  const int lb = g * NL;
+  const int lb = g * NLN, lbB = g * NLN * W2;
 
   // ---- loads ----
   const uint32_t *rec = a.lines + (size_t)nl * REC;
-  uint32_t wB[R * R], wx[R];  // wx: target row masks (single colour) or the duplicate-target word (multi colour)
-  if constexpr (WIDE) {
-    wB[0] = rec[j];
-    wB[1] = rec[j + 16];
-    wB[2] = rec[32 + j];
-    wB[3] = rec[48 + j];
-    wx[0] = rec[mc ? 96 : 64 + j];
-    wx[1] = rec[mc ? 96 : 80 + j];
-  } else {
-    wB[0] = rec[j];
-    wx[0] = rec[mc ? 16 : 16 + j];
+  uint32_t wR[R], wC[R], wx[R];  // wx: target row masks (single colour) or the duplicate-target word (multi colour)
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int line = j + i * G;
+    wR[i] = rec[line];
+    if constexpr (WIDE) {
+      wC[i] = rec[32 + line];
+      wx[i] = rec[mc ? 96 : 64 + line];
+    } else {
+      wC[i] = 0;
+      wx[i] = rec[mc ? 16 : 16 + line];
+    }
   }
   const cell_t *g_pos = reinterpret_cast<const cell_t *>(a.pos);
   const cell_t *g_init = reinterpret_cast<const cell_t *>(a.init);
@@ -1024,8 +1088,8 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   for (int i = 0; i < R; ++i) {
     occ[lb + j + i * G] = 0u;
     nrw[lb + j + i * G] = 0u;
-    lnB[lb * R + j + i * G] = wB[i];
-    if constexpr (WIDE) lnB[lb * R + NL + j + i * G] = wB[2 + i];
+    lnB[lbB + j + i * G] = wR[i];
+    if constexpr (WIDE) lnB[lbB + NLN + j + i * G] = wC[i];
   }
 
   int kind;  // 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells
@@ -1075,9 +1139,9 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
     const uint32_t O = occ[lb + line];
     uint32_t B;
     if constexpr (WIDE) {
-      B = lnB[lb * R + (vert ? NL : 0) + line];
+      B = lnB[lbB + (vert ? NLN : 0) + line];
     } else {
-      const uint32_t w = lnB[lb + line];
+      const uint32_t w = lnB[lbB + line];
       B = vert ? (w >> 16) : (w & 0xffffu);
     }
     const int x0 = vert ? pr[k] : pc[k];
@@ -1122,6 +1186,12 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
     if (a.flags) a.flags[n] = (uint8_t)flags;
   }
 
+  // obstacles | tiles of row r of this board (for the legality mask)
+  auto row_filled = [&](int r) -> uint32_t {
+    const uint32_t w = lnB[lbB + r];
+    return (WIDE ? w : (w & 0xffffu)) | nrw[lb + r];
+  };
+
   if constexpr (EXTRAS) {
     // ---- legality mask of the post-move board (environment.py:149-171) ----
     // A move changes the board iff some tile has a free cell next to it in that direction: in a
@@ -1134,11 +1204,8 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
 #pragma unroll
       for (int k = 0; k < TPL; ++k) {
         const int r = pr[k], c = pc[k];
-        const uint32_t here = lnB[lb * R + r] | nrw[lb + r];  // obstacles | tiles of the tile's row (WIDE: row masks come first)
-        const uint32_t row_mask = WIDE ? here : ((lnB[lb + r] & 0xffffu) | nrw[lb + r]);
-        const int ru = max(r - 1, 0), rd = min(r + 1, S - 1);
-        const uint32_t up = WIDE ? (lnB[lb * R + ru] | nrw[lb + ru]) : ((lnB[lb + ru] & 0xffffu) | nrw[lb + ru]);
-        const uint32_t dn = WIDE ? (lnB[lb * R + rd] | nrw[lb + rd]) : ((lnB[lb + rd] & 0xffffu) | nrw[lb + rd]);
+        const uint32_t row_mask = row_filled(r);
+        const uint32_t up = row_filled(max(r - 1, 0)), dn = row_filled(min(r + 1, S - 1));
         uint32_t m = 0;
         m |= (r > 0 && !((up >> c) & 1u)) ? 1u : 0u;                          // UP
         m |= (r < S - 1 && !((dn >> c) & 1u)) ? 2u : 0u;                      // DOWN
@@ -1178,7 +1245,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
           sum += hasT[k] ? best : 0;
         }
       }
-      for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);  // stays inside the 16-lane group
+      for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);  // stays inside the board's group of lanes
       if (live && j == 0) a.reward[n] = -sum;
     }
   }
@@ -1190,7 +1257,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
 #pragma unroll
       for (int i = 0; i < R; ++i) {
         unsigned char *myrow = my + 3 * mul_s(j + i * G);
-        for (uint32_t m = WIDE ? wB[i] : (wB[0] & 0xffffu); m; m &= m - 1) myrow[3 * ts::lsb(m)] = 1;
+        for (uint32_t m = WIDE ? wR[i] : (wR[i] & 0xffffu); m; m &= m - 1) myrow[3 * ts::lsb(m)] = 1;
       }
 #pragma unroll
       for (int k = 0; k < TPL; ++k)
@@ -1222,7 +1289,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
       }
     }
     wave_sync();
-    if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
+    if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
     if (a.obs_u8) emit_bytes_raw<4, NT>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 
@@ -1251,7 +1318,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
 #pragma unroll
           for (int i = 0; i < R; ++i) {
             const int row0 = mul_s(j + i * G);
-            for (uint32_t m = WIDE ? wB[i] : (wB[0] & 0xffffu); m; m &= m - 1) drop(0, row0 + ts::lsb(m));
+            for (uint32_t m = WIDE ? wR[i] : (wR[i] & 0xffffu); m; m &= m - 1) drop(0, row0 + ts::lsb(m));
           }
 #pragma unroll
           for (int k = 0; k < TPL; ++k) {
@@ -1261,7 +1328,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
         }
         wave_sync();
         const int64_t left = total - p0;
-        emit_bytes_as_f32<NT>(ohimg, dst + p0, (int)(left < kOhPiece ? left : kOhPiece), lane);
+        emit_bytes_as_f32<NT>(ohimg, dst + p0, (int)(left < kOhPiece ? left : kOhPiece), lane, a.emit_edges);
       }
     }
   }
@@ -1465,11 +1532,15 @@ __global__ __launch_bounds__(256) void k_fill_actions(uint8_t *actions, int64_t 
 // ------------------------------------------------------------------------------------------
 thread_local int32_t t_last_hip_error = 0;
 std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_TUNE_MULTI_MIN_BOARDS)
+std::atomic<int64_t> g_lines_lanes{0};  // ts_tuning(TS_TUNE_LINES_LANES): 0 = by tile count, 4 / 8 / 16 = forced where instantiated
+std::atomic<int64_t> g_lines_bpw{0};    // ts_tuning(TS_TUNE_LINES_BPW): 0 = policy, else boards per wave of k_lines (the other lanes idle)
+std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
 std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
 
 int32_t check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
-  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -3 || d->launch_hint > 3 ||
+  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 || d->emit_edges < 0 || d->emit_edges > 4 ||
+      (d->lines_lanes != 0 && d->lines_lanes != 4 && d->lines_lanes != 8 && d->lines_lanes != 16) ||
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;
   if (d->size > TS_MAX_SIZE || d->n_tiles > TS_MAX_TILES || d->n_targets > TS_MAX_TILES) return TS_ERR_LIMIT;
@@ -1624,20 +1695,29 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
   if (!out_of_cache || TS_OOC_WAVES == 0) return {0, 0};
   if (TS_OOC_WAVES > 0) return {TS_OOC_WAVES, TS_OOC_BLOCKS > 0 ? TS_OOC_BLOCKS : 0};
   if (compute_heavy) return {0, 0};
+  // Round 3: with store instructions that cover whole 128-byte lines (emit_bytes_as_f32) a launch tolerates - and wants -
+  // more resident waves than before (cfg4: 7 -> 13 blocks per CU 134 -> 107 us on the box of profiles/r03_emit_edges_ab.log,
+  // cfg2 4 -> 6, 4x4 at 4M boards 12 -> 14, 6x6 7 -> 10, 9x9 / 12x12 7 -> 10); very large chunks (20x20 and up) stay flat.
   if (lines_kernel) {
     if (chunk >= 40u * 1024u) return {1, 4};
-    return {1, chunk < 5u * 1024u ? 12 : chunk < 8u * 1024u ? 10 : 7};
+    if (chunk >= 24u * 1024u) return {1, 7};
+    if (chunk >= 12u * 1024u) return {1, 10};
+    if (chunk >= 8u * 1024u) return {1, 13};
+    return {1, chunk < 5u * 1024u ? 12 : 10};
   }
   // k_small, half waves (32 boards per wave, see small_boards_per_wave): `chunk` is the half wave's output
-  // cfg2 (25.6 KB): on a fast allocation 5 -> 122 us, 4 -> 133, 6 -> 125; on a slow one 5 -> 146, 4 -> 135, 6 -> 148
-  // (profiles/r02_placement_study.log).  Five is a gamble (3 of 8 allocations fast), four the same on both; a caller
-  // that rates its buffers (VecTilerSliderEnv placement_trials) moves up with ts_dims.launch_hint = +1.
-  if (chunk >= 22u * 1024u) return {1, 4};
-  if (chunk >= 16u * 1024u) return {1, 8};                     // 7x7: flat from 6 up
-  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 7 : 10};    // 5x5, 6x6: 7 (10 with more tiles: more loads to hide)
-  if (chunk >= 4u * 1024u) return {1, tiles <= 2 ? 12 : 14};   // 4x4: 4M boards 12 -> 113 us, 10 -> 122, 16 -> 119
+  if (chunk >= 22u * 1024u) return {1, 6};                     // cfg2 (25.6 KB)
+  if (chunk >= 16u * 1024u) return {1, 10};                    // 7x7
+  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 10 : 12};   // 5x5, 6x6
+  if (chunk >= 4u * 1024u) return {1, 14};                     // 4x4
   return {1, 16};  // 2x2, 1x1 (full waves; 3x3's 6.9 KB land in the branch above)
 }
+
+// Which store instructions of a wave's chunk go out as write-back stores instead of nontemporal ones (KArgs.emit_edges):
+// the first and the last one (3) once a chunk is long enough that two instructions are a small part of it - worth 3-10 %
+// from 6x6 up (cfg2 139 -> 125 us, 12x12 77 -> 73, 6x6 71 -> 67, 9x9 83.5 -> 79) -, none for short chunks (a 4x4 half
+// wave has six store instructions: 115 -> 194 us with two of them write-back).  profiles/r03_emit_edges_ab.log
+uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= 8u * 1024u ? 3u : 0u; }
 
 // Boards per wave of k_small.  Beyond the Infinity Cache the register-path kernels run HALF waves —
 // 32 boards, the upper lanes idle — once a full wave would write 8 KB or more: the transition
@@ -1694,6 +1774,10 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const uint64_t per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
     a.nt = per_board * (uint64_t)d->n_boards > (uint64_t)g_nt_threshold_bytes.load(std::memory_order_relaxed) ? 1u : 0u;
   }
+  if (a.nt) {
+    const int64_t forced = g_emit_edges.load(std::memory_order_relaxed);
+    a.emit_edges = d->emit_edges > 0 ? (uint32_t)(d->emit_edges - 1) : forced >= 0 && forced <= 3 ? (uint32_t)forced : 0xffu;  // 0xff: by shape, below
+  }
   hipStream_t hs = (hipStream_t)stream;
 
   if (S <= 8) {
@@ -1723,6 +1807,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board);
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
+    if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
     apply_launch_hint(res, d->launch_hint);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
@@ -1744,18 +1829,36 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     // step / reset / encode (+ legality mask, reward, one-hot) with the level's precomputed line masks: k_lines
     const bool wide = S > 16;
     a.lines = st->lines;
-    const int per_lane = ((T > Tt ? T : Tt) + kLinesG - 1) / kLinesG;
+    // Lanes per board: 16 lanes (4 boards per wave) only pay when there are tiles to deal over them and a wave's chunk of
+    // output is not tiny; 4 lanes exist up to 16x16 only (above, four lanes would own eight lines each and a wave's image
+    // would not fit its LDS carve).  ts_dims.lines_lanes / ts_tuning(TS_TUNE_LINES_LANES) force a form.
+    const int maxT = T > Tt ? T : Tt;
+    // profiles/r03_lines_lanes_ab.log: 9x9 96 -> 89 us with 4 lanes, 10x10 / 5 tiles 83 -> 77 with 8; from 12x12 on the
+    // 16-lane form wins again (its chunk per wave is already 7 KB and more), above 16x16 always
+    int lpb = 16;
+    if (S <= 10 && maxT <= 16) lpb = 8;
+    if (S <= 10 && maxT <= 4) lpb = 4;
+    if (const int64_t forced = g_lines_lanes.load(std::memory_order_relaxed); forced == 4 || forced == 8 || forced == 16) lpb = (int)forced;
+    if (d->lines_lanes) lpb = d->lines_lanes;
+    if (lpb == 4 && wide) lpb = 8;
+    if (lpb < 16 && (maxT + lpb - 1) / lpb > 2) lpb = 16;  // instantiated: 1 or 2 tiles per lane for 4 and 8 lanes per board
+    const int bpw_max = kWave / lpb;
+    const int per_lane = (maxT + lpb - 1) / lpb;
     int tpl = 1;
     while (tpl < per_lane) tpl <<= 1;
-    a.lds_stage_off = align16((uint32_t)(kLinesBPW * 3 * C));
+    const int nln = wide ? 32 : 16;
+    a.lds_stage_off = align16((uint32_t)(bpw_max * 3 * C));
     const bool lines_extras = a.valid || a.reward || a.onehot;
-    a.lds_oh_off = a.lds_stage_off + (uint32_t)(kLinesBPW * kLinesG * (wide ? 2 * (2 + 1 + 1) : 3) * 4) +
-                   (a.reward && !d->multi_color ? align16((uint32_t)(kLinesBPW * Tt * 2)) : 0u);
-    a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
-    a.bpw = (a.nt && TS_LINES_OOC_BPW > 0) ? TS_LINES_OOC_BPW : kLinesBPW;
+    a.lds_oh_off = a.lds_stage_off + (uint32_t)(bpw_max * nln * ((wide ? 2 : 1) + 1 + 1) * 4) +
+                   (a.reward && !d->multi_color ? align16((uint32_t)(bpw_max * Tt * 2)) : 0u);
+    a.lds_wave_bytes = align16(a.lds_oh_off) + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
+    a.lds_oh_off = align16(a.lds_oh_off);
+    a.bpw = (a.nt && TS_LINES_OOC_BPW > 0 && TS_LINES_OOC_BPW <= bpw_max) ? TS_LINES_OOC_BPW : (uint32_t)bpw_max;
+    if (const int64_t forced = g_lines_bpw.load(std::memory_order_relaxed); forced >= 1 && forced <= bpw_max) a.bpw = (uint32_t)forced;
     Residency res = ooc_residency(a.nt != 0, true, false,
                                         (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)), T);
     apply_launch_hint(res, d->launch_hint);
+    if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
@@ -1767,20 +1870,27 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const uint32_t inv_s = (uint32_t)((65536 + S - 1) / S);
     using LinesKernel = void (*)(const KArgs, const int, const uint32_t);
     LinesKernel k = nullptr;
-    auto pick = [&](auto tpl_c) -> LinesKernel {
-      constexpr int TPLC = decltype(tpl_c)::value;
+    auto pick = [&](auto lpb_c, auto tpl_c) -> LinesKernel {
+      constexpr int LPBC = decltype(lpb_c)::value, TPLC = decltype(tpl_c)::value;
       if (lines_extras)
-        return wide ? (a.nt ? k_lines<true, TPLC, true, true> : k_lines<true, TPLC, false, true>)
-                    : (a.nt ? k_lines<false, TPLC, true, true> : k_lines<false, TPLC, false, true>);
-      return wide ? (a.nt ? k_lines<true, TPLC, true, false> : k_lines<true, TPLC, false, false>)
-                  : (a.nt ? k_lines<false, TPLC, true, false> : k_lines<false, TPLC, false, false>);
+        return wide ? (a.nt ? k_lines<true, (LPBC < 8 ? 8 : LPBC), TPLC, true, true> : k_lines<true, (LPBC < 8 ? 8 : LPBC), TPLC, false, true>)
+                    : (a.nt ? k_lines<false, LPBC, TPLC, true, true> : k_lines<false, LPBC, TPLC, false, true>);
+      return wide ? (a.nt ? k_lines<true, (LPBC < 8 ? 8 : LPBC), TPLC, true, false> : k_lines<true, (LPBC < 8 ? 8 : LPBC), TPLC, false, false>)
+                  : (a.nt ? k_lines<false, LPBC, TPLC, true, false> : k_lines<false, LPBC, TPLC, false, false>);
     };
-    switch (tpl) {
-      case 1: k = pick(std::integral_constant<int, 1>{}); break;
-      case 2: k = pick(std::integral_constant<int, 2>{}); break;
-      case 4: k = pick(std::integral_constant<int, 4>{}); break;
-      case 8: k = pick(std::integral_constant<int, 8>{}); break;
-      default: k = pick(std::integral_constant<int, 16>{}); break;
+    using std::integral_constant;
+    if (lpb == 16) {
+      switch (tpl) {
+        case 1: k = pick(integral_constant<int, 16>{}, integral_constant<int, 1>{}); break;
+        case 2: k = pick(integral_constant<int, 16>{}, integral_constant<int, 2>{}); break;
+        case 4: k = pick(integral_constant<int, 16>{}, integral_constant<int, 4>{}); break;
+        case 8: k = pick(integral_constant<int, 16>{}, integral_constant<int, 8>{}); break;
+        default: k = pick(integral_constant<int, 16>{}, integral_constant<int, 16>{}); break;
+      }
+    } else if (lpb == 8) {
+      k = tpl == 1 ? pick(integral_constant<int, 8>{}, integral_constant<int, 1>{}) : pick(integral_constant<int, 8>{}, integral_constant<int, 2>{});
+    } else {
+      k = tpl == 1 ? pick(integral_constant<int, 4>{}, integral_constant<int, 1>{}) : pick(integral_constant<int, 4>{}, integral_constant<int, 2>{});
     }
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a, S, inv_s);
   }
@@ -1945,7 +2055,11 @@ int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void
 }
 
 int64_t ts_tuning(int32_t key, int64_t value) {
-  std::atomic<int64_t> *knob = key == TS_TUNE_MULTI_MIN_BOARDS ? &g_multi_min_boards : key == TS_TUNE_NT_THRESHOLD_BYTES ? &g_nt_threshold_bytes : nullptr;
+  std::atomic<int64_t> *knob = key == TS_TUNE_MULTI_MIN_BOARDS ? &g_multi_min_boards
+                               : key == TS_TUNE_NT_THRESHOLD_BYTES ? &g_nt_threshold_bytes
+                               : key == TS_TUNE_LINES_LANES ? &g_lines_lanes
+                               : key == TS_TUNE_LINES_BPW ? &g_lines_bpw
+                               : key == TS_TUNE_EMIT_EDGES ? &g_emit_edges : nullptr;
   if (!knob) return -1;
   return value >= 0 ? knob->exchange(value) : knob->load();
 }

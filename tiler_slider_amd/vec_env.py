@@ -90,15 +90,15 @@ class VecTilerSliderEnv:
                       overwrites the same tensor).  With 2, the tensor returned by step k stays
                       intact while step k+1 runs, so a consumer on another stream — the RCCL
                       all-gather of tiler_slider_amd.distributed — can overlap with the next step.
-        placement_trials : for batches whose outputs do not fit the 256 MiB Infinity Cache the step time
-                      depends on WHERE the observation (and one-hot) buffers were allocated: the same kernel
-                      on the same data runs at either of two speeds, up to 17 % apart, stable for the life of
-                      the allocation (profiles/r02_placement_study.log).  With k > 1 the
-                      constructor allocates up to k candidate sets of those buffers, times a few steps of the
-                      real kernel on each (the state is restored afterwards) and keeps the fastest; the others
-                      are released.  Per candidate it also rates one resident block per CU less and more than
-                      the library's policy (`ts_dims.launch_hint`) and keeps the best of the three.  Costs k times the output memory during construction and a few
-                      milliseconds; no effect on results.  Default 1 (off).  `placement_report` holds the timings.
+        placement_trials : for batches whose outputs do not fit the 256 MiB Infinity Cache the step time depends on WHERE
+                      the observation (and one-hot) buffers were allocated and on the launch policy that suits them (the
+                      same kernel on the same data runs up to 20 % apart between allocations).
+                      1 (default): the constructor rates a handful of launch policies (the per-call fields of ts_dims:
+                      resident blocks per CU, write-back edge stores, lanes per board) with the real step kernel on the
+                      buffers it allocated - about 100 launches, state restored afterwards - and keeps the best; k > 1:
+                      the same for up to k candidate sets of output buffers, keeping the best set (k times the output
+                      memory during construction); 0: no measuring, the library's static policy.  No effect on results.
+                      `placement_report` holds the timings, the static policy's among them.
         host_mapped : keep every buffer in pinned host memory that the GPU reads and writes in
                       place (zero-copy).  For a handful of boards driven move by move from Python
                       (the one-board adapters): a step is then one launch plus one stream
@@ -261,7 +261,7 @@ class VecTilerSliderEnv:
         self._mode = _cabi.MODE_AUTORESET if self.auto_reset else _cabi.MODE_STRICT
         self._bind_outputs()
         self.placement_report = None
-        if int(placement_trials) > 1:
+        if int(placement_trials) >= 1:
             self._tune_placement(int(placement_trials))
         self.observation_shape = (self.size, self.size, 3)  # per board, environment.py:59
         self._started = False
@@ -275,9 +275,12 @@ class VecTilerSliderEnv:
         self._obs = self._obs_ring[0]
         self._out = self._outs[0]
 
-    # Beyond the Infinity Cache the fused step runs at one of two speeds depending on the allocation of its
-    # large output buffers (cfg2: 124 vs 146 us, three of eight allocations fast; a dense fill of the same
-    # buffers does not see it).  Nothing in the virtual address tells them apart, so: try a few, keep the best.
+    # Beyond the Infinity Cache the step time depends on WHERE the large output buffers were allocated and, with that, on
+    # the launch policy that suits them (resident blocks per CU, write-back edge stores, lanes per board): the same kernel
+    # on the same data runs up to 20 % apart between allocations and boxes.  Nothing in the virtual
+    # address tells them apart, so the constructor measures: a coordinate search over the per-call policy fields of
+    # ts_dims on the real step kernel (~100 launches, state restored), and with placement_trials = k > 1 the same for up
+    # to k candidate sets of output buffers, keeping the best.
     _PLACEMENT_MIN_BYTES = 256 << 20
 
     def _tune_placement(self, trials):
@@ -296,18 +299,43 @@ class VecTilerSliderEnv:
         acts = self._empty(N, torch.uint8)
         self._call("ts_fill_actions", N, C.c_uint64(0xAC710005), 0, 0, _ptr(acts))
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        candidates, times, hints = [(self._obs_ring, self._onehot)], [], []
+        candidates, times, policies, policy_us = [(self._obs_ring, self._onehot)], [], [], []
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        d = self._dims
 
-        def rate(out):
-            for i in range(3):
-                _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(out), stream), "ts_step")
-            ev0.record()
-            for i in range(8):
-                _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(out), stream), "ts_step")
-            ev1.record()
-            ev1.synchronize()
-            return ev0.elapsed_time(ev1) * 1e3 / 8
+        def rate(policy):
+            """us per step with ts_dims policy fields (launch_hint, emit_edges, lines_lanes); a set of buffers counts as its
+            slowest member."""
+            d.launch_hint, d.emit_edges, d.lines_lanes = policy
+            worst = 0.0
+            for out in self._outs:
+                for i in range(3):
+                    _cabi.check(L.ts_step(C.byref(d), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(out), stream), "ts_step")
+                ev0.record()
+                for i in range(8):
+                    _cabi.check(L.ts_step(C.byref(d), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(out), stream), "ts_step")
+                ev1.record()
+                ev1.synchronize()
+                worst = max(worst, ev0.elapsed_time(ev1) * 1e3 / 8)
+            return worst
+
+        def search():
+            """Coordinate search from the library's own policy (0, 0, 0): resident blocks per CU, then the edge stores, then
+            (boards above 8x8) the lanes per board, then one refinement of the first."""
+            seen = {}
+
+            def best_of(cands):
+                for c in cands:
+                    if c not in seen:
+                        seen[c] = rate(c)
+                return min(cands, key=seen.__getitem__)
+
+            cur = best_of([(h, 0, 0) for h in (0, -2, 2, 4)])
+            cur = best_of([cur] + [(cur[0], e, 0) for e in (1, 4)])
+            if self.size > 8:
+                cur = best_of([cur] + [(cur[0], cur[1], ln) for ln in (4, 8, 16)])
+            cur = best_of([cur] + [(cur[0] + dh, cur[1], cur[2]) for dh in (-1, 1) if -8 <= cur[0] + dh <= 8])
+            return cur, seen[cur], seen[(0, 0, 0)]
 
         with torch.cuda.device(self.device):
             for k in range(trials):
@@ -316,16 +344,8 @@ class VecTilerSliderEnv:
                                        torch.zeros_like(self._onehot) if self._onehot is not None else None))
                 self._obs_ring, self._onehot = candidates[k]
                 self._bind_outputs()
-                # How many waves a CU should keep resident depends on the allocation too (cfg2: five on a fast one,
-                # four on a slow one: 146 -> 135 us): rate the library's policy and one block per CU less / more
-                # (ts_dims.launch_hint).  Every buffer of the ring is rated; a set counts as its slowest member.
-                per_hint = {}
-                for hint in (0, -1, 1):
-                    self._dims.launch_hint = hint
-                    per_hint[hint] = max(rate(out) for out in self._outs)
-                hint = min(per_hint, key=per_hint.__getitem__)
-                times.append(per_hint[hint])
-                hints.append(hint)
+                pol, us, base_us = search()
+                times.append(us), policies.append(pol), policy_us.append(base_us)
                 # two clearly separated speeds seen and the current one is of the fast kind: stop looking
                 if len(times) >= 2 and times[-1] <= min(times) * 1.02 and max(times) >= min(times) * 1.06:
                     break
@@ -341,9 +361,10 @@ class VecTilerSliderEnv:
             if t is not None:
                 t.zero_()
         self._bind_outputs()
-        self._dims.launch_hint = hints[best]
-        self.placement_report = {"us_per_step": [round(t, 2) for t in times], "launch_hint": hints, "chosen": best,
-                                 "trials": len(times)}
+        d.launch_hint, d.emit_edges, d.lines_lanes = policies[best]
+        self.placement_report = {"us_per_step": [round(t, 2) for t in times], "library_policy_us": [round(t, 2) for t in policy_us],
+                                 "policy": [{"launch_hint": p[0], "emit_edges": p[1], "lines_lanes": p[2]} for p in policies],
+                                 "launch_hint": [p[0] for p in policies], "chosen": best, "trials": len(times)}
 
     # buffers live on the GPU, or (host_mapped) in pinned host memory the GPU addresses directly
     def _pin(self, t):

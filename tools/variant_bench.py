@@ -62,6 +62,7 @@ def run(a):
                                        auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"])
         keep.append(env)
     env.reset()
+    env._dims.launch_hint = a.hint
     stream = torch.cuda.current_stream(dev).cuda_stream
     ring = []
     for i in range(16):
@@ -131,7 +132,7 @@ def run(a):
                 times[name].append(e0.elapsed_time(e1) * 1e3 / a.steps)
     bps = bench.algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
     res = {}
-    print(f"{a.config}: {n} boards, {bps} B/board-step, {a.rounds} rounds x {a.steps} steps")
+    print(f"{a.config}: {n} boards, {bps} B/board-step, {a.rounds} rounds x {a.steps} steps, launch_hint {a.hint}")
     for name in names:
         med, mn = statistics.median(times[name]), min(times[name])
         res[name] = {"flags": manifest[name], "median_us": med, "min_us": mn, "GBps_median": bps * n / med / 1e3}
@@ -153,6 +154,7 @@ if __name__ == "__main__":
     r.add_argument("--only")
     r.add_argument("--shape", help="S,T,K,N: ad-hoc shape registered under --config's name")
     r.add_argument("--no-check", action="store_true")
+    r.add_argument("--hint", type=int, default=0, help="ts_dims.launch_hint for every variant")
     r.add_argument("--tag", default="")
     r.add_argument("--placement", type=int, default=0, help="use the K-th allocation of the environment")
     r.add_argument("--pick", choices=["slowest", "fastest"], help="with --placement K: rate the K+1 allocations, use that one")
