@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--policy", default=None,
                     help="launch_hint,emit_edges,lines_lanes: fix the per-call launch policy of ts_dims (use with --placement-trials 0 "
                          "to profile exactly the launches a tuned run settled on)")
+    ap.add_argument("--output-memory", choices=["torch", "contiguous"], default="torch",
+                    help="VecTilerSliderEnv(output_memory=...): physically contiguous output buffers beyond the Infinity Cache, or torch's allocator")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-halves-on-two-streams figure")
     ap.add_argument("--no-sibling", action="store_true", help="skip the out-of-cache sibling of a cache-resident config")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -222,7 +224,7 @@ def main():
     env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
                                    seed=LEVEL_SEED, multi_color=True, max_steps=2**30, board_offset=rank * n,
                                    device=device, auto_reset=True, with_reward=cfg["reward"],
-                                   with_onehot=cfg["onehot"], placement_trials=args.placement_trials)
+                                   with_onehot=cfg["onehot"], placement_trials=args.placement_trials, output_memory=args.output_memory)
     if args.policy:
         env._dims.launch_hint, env._dims.emit_edges, env._dims.lines_lanes = (int(x) for x in args.policy.split(","))
     env.reset()
@@ -317,7 +319,7 @@ def main():
         big = VecTilerSliderEnv.random(n_big, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
                                        seed=LEVEL_SEED, multi_color=True, max_steps=2**30, device=device, auto_reset=True,
                                        with_reward=cfg["reward"], with_onehot=cfg["onehot"],
-                                       placement_trials=args.placement_trials)
+                                       placement_trials=args.placement_trials, output_memory=args.output_memory)
         big.reset()
         acts = []
         for i in range(4):
@@ -413,7 +415,7 @@ def main():
                        "launch": "hipGraph" if graph is not None else "eager",
                        # construction-time choice among candidate allocations of the output buffers (outside the
                        # timed region; only for batches beyond the Infinity Cache): VecTilerSliderEnv docstring
-                       "placement_trials": args.placement_trials, "placement": env.placement_report,
+                       "placement_trials": args.placement_trials, "placement": env.placement_report, "output_memory": args.output_memory,
                        "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges,
                                          "lines_lanes": env._dims.lines_lanes},
                        "parallelism": f"boards sharded over {world} GPU(s), no data-path collective",
@@ -477,12 +479,16 @@ def time_config(name, trials, steps, device, L, stream):
                        + (", + one-hot + Manhattan reward" if cfg["onehot"] else ""),
            "kernel": dominant_kernel(cfg, n, L), "algorithmic_bytes_per_board_step": bps, "algorithmic_bytes_per_launch": bps * n,
            "steps": steps}
-    for key, k in (("library_policy", 0), ("first_allocation", 1), ("tuned", trials)):
+    # library_policy: static launch policy, no measuring at construction; first_allocation: the class default (launch policy
+    # rated at construction on the buffers first allocated); tuned: + candidate buffers; *_contiguous_memory: the class default
+    # with the output buffers in physically contiguous memory (output_memory="contiguous": the same speed every time)
+    for key, k, mem in (("library_policy", 0, "torch"), ("first_allocation", 1, "torch"), ("tuned", trials, "torch"),
+                        ("first_allocation_contiguous_memory", 1, "contiguous")):
         if key == "tuned" and trials <= 1:
-            break
+            continue
         env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"], seed=LEVEL_SEED,
                                        multi_color=True, max_steps=2**30, device=device, auto_reset=True, with_reward=cfg["reward"],
-                                       with_onehot=cfg["onehot"], placement_trials=k)
+                                       with_onehot=cfg["onehot"], placement_trials=k, output_memory=mem)
         env.reset()
         for i in range(10):
             env.step_async(acts[i & 3])

@@ -1696,18 +1696,19 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
   if (TS_OOC_WAVES > 0) return {TS_OOC_WAVES, TS_OOC_BLOCKS > 0 ? TS_OOC_BLOCKS : 0};
   if (compute_heavy) return {0, 0};
   // Round 3: with store instructions that cover whole 128-byte lines (emit_bytes_as_f32) a launch tolerates - and wants -
-  // more resident waves than before (cfg4: 7 -> 13 blocks per CU 134 -> 107 us on the box of profiles/r03_emit_edges_ab.log,
-  // cfg2 4 -> 6, 4x4 at 4M boards 12 -> 14, 6x6 7 -> 10, 9x9 / 12x12 7 -> 10); very large chunks (20x20 and up) stay flat.
+  // more resident waves than before (profiles/r03_emit_edges_ab.log, r03_residency_sweep.log; blocks per CU, us per step):
+  // cfg4 7 -> 17 (134 -> 103), cfg2 4 -> 8 (139 -> 113), 4x4 at 4M boards 12 -> 14, 6x6 7 -> 10, 7x7 8 -> 14, 14x14 7 -> 18,
+  // 9x9 / 12x12 7 -> 10 / 12; very large chunks (16x16 with 8 boards per wave, 20x20 and up) are flat from 6 on.
   if (lines_kernel) {
     if (chunk >= 40u * 1024u) return {1, 4};
     if (chunk >= 24u * 1024u) return {1, 7};
     if (chunk >= 12u * 1024u) return {1, 10};
-    if (chunk >= 8u * 1024u) return {1, 13};
-    return {1, chunk < 5u * 1024u ? 12 : 10};
+    if (chunk >= 8u * 1024u) return {1, 18};
+    return {1, 12};
   }
   // k_small, half waves (32 boards per wave, see small_boards_per_wave): `chunk` is the half wave's output
-  if (chunk >= 22u * 1024u) return {1, 6};                     // cfg2 (25.6 KB)
-  if (chunk >= 16u * 1024u) return {1, 10};                    // 7x7
+  if (chunk >= 22u * 1024u) return {1, 8};                     // cfg2 (25.6 KB): 2 blocks per CU 247 us, 4: 138, 6: 120, 8: 113
+  if (chunk >= 16u * 1024u) return {1, 14};                    // 7x7
   if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 10 : 12};   // 5x5, 6x6
   if (chunk >= 4u * 1024u) return {1, 14};                     // 4x4
   return {1, 16};  // 2x2, 1x1 (full waves; 3x3's 6.9 KB land in the branch above)

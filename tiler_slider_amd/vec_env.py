@@ -75,7 +75,7 @@ class VecTilerSliderEnv:
     def __init__(self, size, blocked_locations=None, initial_locations=None, target_locations=None,
                  multi_color=False, max_steps=100, *, device=None, strict=False, auto_reset=False,
                  with_reward=False, with_onehot=False, with_valid_moves=False, obs_dtype="float32",
-                 host_mapped=False, obs_buffers=1, placement_trials=1):
+                 host_mapped=False, obs_buffers=1, placement_trials=1, output_memory="torch"):
         """blocked/initial/target_locations: one list of (row, col) per board.
 
         strict      : raise the reference's RuntimeError when any board is stepped after done
@@ -99,6 +99,16 @@ class VecTilerSliderEnv:
                       the same for up to k candidate sets of output buffers, keeping the best set (k times the output
                       memory during construction); 0: no measuring, the library's static policy.  No effect on results.
                       `placement_report` holds the timings, the static policy's among them.
+        output_memory : where the large output buffers (observations, one-hot planes) live when they do not fit the
+                      Infinity Cache.  "torch" (default): torch's caching allocator.  "contiguous": physically contiguous
+                      device memory (hipExtMallocWithFlags(hipDeviceMallocContiguous)), falling back to torch when that
+                      fails.  A store pattern of many concurrent streams - what the step kernels' waves produce - runs at
+                      one of two speeds on ordinary allocations, up to 17 % apart, decided by the physical pages behind
+                      the buffer (5.8 or 6.8 TB/s in the store-only probe; different windows of ONE allocation differ);
+                      contiguous memory gives the same speed every time (6.55 TB/s in the probe, every candidate of a
+                      bench run within 1 %), which is NOT the fast one: cfg2 123 us where ordinary allocations gave 120-126,
+                      cfg4 114-117 where they gave 108-113 (profiles/r03_alloc_lottery.log).  For reproducible timings,
+                      not for speed.  Smaller outputs always come from torch's allocator.
         host_mapped : keep every buffer in pinned host memory that the GPU reads and writes in
                       place (zero-copy).  For a handful of boards driven move by move from Python
                       (the one-board adapters): a step is then one launch plus one stream
@@ -110,7 +120,7 @@ class VecTilerSliderEnv:
         target_locations = target_locations if target_locations is not None else [[] for _ in range(n)]
         blk, init, tgt = pack_levels(size, blocked_locations, initial_locations or [], target_locations)
         self._setup(size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-                    with_onehot, with_valid_moves, obs_dtype, host_mapped, obs_buffers, placement_trials)
+                    with_onehot, with_valid_moves, obs_dtype, host_mapped, obs_buffers, placement_trials, output_memory)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -122,7 +132,7 @@ class VecTilerSliderEnv:
         self._setup(size, blk, init, tgt, multi_color, max_steps, kw.pop("device", None), kw.pop("strict", False),
                     kw.pop("auto_reset", False), kw.pop("with_reward", False), kw.pop("with_onehot", False),
                     kw.pop("with_valid_moves", False), kw.pop("obs_dtype", "float32"), kw.pop("host_mapped", False),
-                    kw.pop("obs_buffers", 1), kw.pop("placement_trials", 1))
+                    kw.pop("obs_buffers", 1), kw.pop("placement_trials", 1), kw.pop("output_memory", "torch"))
         if kw:
             raise TypeError(f"unexpected arguments {sorted(kw)}")
         if validate:
@@ -212,7 +222,8 @@ class VecTilerSliderEnv:
 
     # ------------------------------------------------------------------ setup
     def _setup(self, size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-               with_onehot, with_valid_moves, obs_dtype="float32", host_mapped=False, obs_buffers=1, placement_trials=1):
+               with_onehot, with_valid_moves, obs_dtype="float32", host_mapped=False, obs_buffers=1, placement_trials=1,
+               output_memory="torch"):
         L = _cabi.lib()  # raises when the HIP library is missing: no fallback
         self.device = _resolve_device(device)
         self.host_mapped = bool(host_mapped)
@@ -241,12 +252,15 @@ class VecTilerSliderEnv:
         self.obs_dtype = obs_dtype
         if int(obs_buffers) < 1:
             raise ValueError("obs_buffers must be >= 1")
-        self._obs_ring = [self._zeros((N, self.size, self.size, 3), obs_dtype) for _ in range(int(obs_buffers))]
+        if output_memory not in ("torch", "contiguous"):
+            raise ValueError("output_memory must be 'torch' or 'contiguous'")
+        self.output_memory = output_memory
+        self._obs_ring = [self._big_zeros((N, self.size, self.size, 3), obs_dtype) for _ in range(int(obs_buffers))]
         self._obs_slot = 0
         self._obs = self._obs_ring[0]  # always the buffer the latest reset() / step() wrote
         self.onehot_channels = L.ts_onehot_channels(C.byref(self._dims))
         self._reward = self._zeros(N, torch.int32) if with_reward else None
-        self._onehot = (self._zeros((N, self.onehot_channels, self.size, self.size), torch.float32)
+        self._onehot = (self._big_zeros((N, self.onehot_channels, self.size, self.size), torch.float32)
                         if with_onehot else None)
         self._valid = self._zeros(N, torch.uint8) if with_valid_moves else None
         # per-level tables of the large-board kernel (include/tiler_slider.h: ts_prepare): the level
@@ -330,18 +344,18 @@ class VecTilerSliderEnv:
                         seen[c] = rate(c)
                 return min(cands, key=seen.__getitem__)
 
-            cur = best_of([(h, 0, 0) for h in (0, -2, 2, 4)])
+            cur = best_of([(h, 0, 0) for h in (0, -2, 2, 4, 8)])
             cur = best_of([cur] + [(cur[0], e, 0) for e in (1, 4)])
             if self.size > 8:
                 cur = best_of([cur] + [(cur[0], cur[1], ln) for ln in (4, 8, 16)])
-            cur = best_of([cur] + [(cur[0] + dh, cur[1], cur[2]) for dh in (-1, 1) if -8 <= cur[0] + dh <= 8])
+            cur = best_of([cur] + [(cur[0] + dh, cur[1], cur[2]) for dh in (-1, 1, 2) if -8 <= cur[0] + dh <= 8])
             return cur, seen[cur], seen[(0, 0, 0)]
 
         with torch.cuda.device(self.device):
             for k in range(trials):
                 if k:
-                    candidates.append(([torch.zeros_like(o) for o in self._obs_ring],
-                                       torch.zeros_like(self._onehot) if self._onehot is not None else None))
+                    candidates.append(([self._big_zeros(tuple(o.shape), o.dtype) for o in self._obs_ring],
+                                       self._big_zeros(tuple(self._onehot.shape), torch.float32) if self._onehot is not None else None))
                 self._obs_ring, self._onehot = candidates[k]
                 self._bind_outputs()
                 pol, us, base_us = search()
@@ -377,6 +391,15 @@ class VecTilerSliderEnv:
         if self.host_mapped:
             return self._pin(torch.zeros(shape, dtype=dtype))
         return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def _big_zeros(self, shape, dtype):
+        """Output buffers: beyond the Infinity Cache from physically contiguous memory (see `output_memory`)."""
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        if not self.host_mapped and self.output_memory == "contiguous" and nbytes > self._PLACEMENT_MIN_BYTES:
+            t = _contiguous_zeros(tuple(shape), dtype, self.device)
+            if t is not None:
+                return t
+        return self._zeros(shape, dtype)
 
     def _empty(self, shape, dtype):
         if self.host_mapped:
@@ -584,6 +607,48 @@ class VecTilerSliderEnv:
     def _require_open(self):
         if self._closed:
             raise RuntimeError("environment is closed")
+
+
+class _ContiguousBuffer:
+    """Device memory from hipExtMallocWithFlags(hipDeviceMallocContiguous): physically contiguous VRAM, exposed to torch
+    through __cuda_array_interface__ (torch.as_tensor keeps this object alive for as long as the tensor lives)."""
+
+    _hip = None
+
+    def __init__(self, nbytes, device):
+        cls = type(self)
+        if cls._hip is None:
+            lib = C.CDLL("libamdhip64.so")
+            lib.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+            lib.hipFree.argtypes = [C.c_void_p]
+            cls._hip = lib
+        p = C.c_void_p()
+        with torch.cuda.device(device):
+            rc = cls._hip.hipExtMallocWithFlags(C.byref(p), nbytes, 0x4)  # hipDeviceMallocContiguous
+        if rc != 0 or not p.value:
+            raise MemoryError(f"hipExtMallocWithFlags(contiguous, {nbytes} B) failed with {rc}")
+        self.ptr, self.nbytes, self.device = p.value, nbytes, device
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (p.value, False), "version": 2, "strides": None}
+
+    def __del__(self):
+        try:
+            if getattr(self, "ptr", None):
+                type(self)._hip.hipFree(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def _contiguous_zeros(shape, dtype, device):
+    """A zeroed tensor in physically contiguous device memory, or None when the runtime cannot provide it."""
+    n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    try:
+        buf = _ContiguousBuffer(n, device)
+        t = torch.as_tensor(buf, device=device).view(dtype).view(shape)
+    except Exception:  # no such flag in this runtime, fragmented VRAM, ...: the caching allocator will do
+        return None
+    t.zero_()
+    return t
 
 
 def _resolve_device(device):

@@ -20,7 +20,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 print("   S    T   boards   lanes: us/step at launch_hint -1 / 0 / +1 (frac of 8 TB/s at the best)")
 for S, T, K in SHAPES:
     n = max(4096, (500_000_000 // (12 * S * S)) // 256 * 256)
-    env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=3, multi_color=True, max_steps=2**30, auto_reset=True)
+    env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=3, multi_color=True, max_steps=2**30, auto_reset=True, placement_trials=0)
     env.reset()
     act = torch.randint(0, 4, (n,), dtype=torch.uint8, device=env.device)
     bps = bench.algorithmic_bytes_per_board_step(S, T, False, False) + (T * 2 if S > 16 else 0)
