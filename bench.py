@@ -433,7 +433,7 @@ def main():
                          # cache / fabric write rate, not at the HBM rate: see "hbm_sibling"
                          "cache_resident": cache_resident},
         }
-        rec = pmc_traffic(args.config, n)
+        rec = pmc_traffic(args.config if n == CONFIGS[args.config]["boards"] else args.config + "_sibling_4m", n)
         if rec is not None:
             line["roofline"]["traffic"] = rec["write_bytes"] + rec["fetch_bytes_x2"]
             line["roofline"]["traffic_source"] = ("rocprofv3 --pmc WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read "

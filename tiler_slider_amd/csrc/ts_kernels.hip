@@ -58,7 +58,7 @@
 #ifndef TS_EMIT_EDGE_PLAIN  // experiment: first and last store instruction of a chunk as write-back stores
 #define TS_EMIT_EDGE_PLAIN 0
 #endif
-#ifndef TS_ABLATE_DENSE  // store-only ablation writes observation-like data (1 byte in 8 non-zero) instead of near-zeros
+#ifndef TS_ABLATE_DENSE  // store-only ablation: 0 = near-zeros, 1 = observation-like data (1 byte in 8 non-zero), 2 = every float non-zero
 #define TS_ABLATE_DENSE 0
 #endif
 #ifndef TS_ABLATE_LOADS
@@ -407,7 +407,8 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   if (a.obs) {
     for (int c0 = 0; c0 < nb; c0 += kObsBoards) {
       if (c0) wave_sync();
-      for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = TS_ABLATE_DENSE ? make_uint4(1, 0, 0x0200, 0) : make_uint4(0, 0, lane & 1, 0);
+      for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = TS_ABLATE_DENSE == 2 ? make_uint4(0x04030201u + lane, 0x08070605u, 0x0c0b0a09u + off, 0x100f0e0du)
+                                                                                                            : TS_ABLATE_DENSE ? make_uint4(1, 0, 0x0200, 0) : make_uint4(0, 0, lane & 1, 0);
 #if TS_ABLATE_LOADS
       {  // + the state loads of a plain step, consumed by one LDS byte
         const int64_t nl = (n0 + lane) < a.N ? n0 + lane : a.N - 1;
