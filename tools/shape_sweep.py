@@ -6,14 +6,15 @@ import torch
 import bench
 from tiler_slider_amd import VecTilerSliderEnv
 
-SHAPES = [(3, 1, 0), (4, 2, 2), (4, 4, 2), (5, 2, 3), (5, 6, 3), (6, 3, 4), (7, 5, 6), (8, 4, 8), (8, 12, 8), (9, 4, 9),
-          (10, 5, 10), (12, 8, 16), (14, 20, 20), (15, 32, 24), (16, 16, 24), (20, 10, 40), (24, 30, 60), (32, 32, 100)]
+SHAPES = [(3, 1, 0), (4, 2, 2), (4, 4, 2), (5, 2, 3), (5, 6, 3), (6, 3, 4), (7, 5, 6), (8, 4, 8), (8, 12, 8), (8, 20, 10), (9, 1, 9), (9, 4, 9),
+          (10, 5, 10), (11, 6, 8), (12, 8, 16), (13, 3, 10), (14, 20, 20), (15, 32, 24), (16, 4, 24), (16, 16, 24), (20, 1, 1), (20, 10, 40), (24, 30, 60),
+          (32, 4, 100), (32, 32, 100)]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 print("   S    T    K    boards   out MB    us/step   steps/s    alg GB/s   % of 8 TB/s")
 for S, T, K in SHAPES:
     n = max(4096, min(1 << 20, (500_000_000 // (12 * S * S)) // 256 * 256))
     env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=3, multi_color=True, max_steps=2**30,
-                                   auto_reset=True)
+                                   auto_reset=True, placement_trials=int(os.environ.get('TS_SWEEP_TRIALS', '0')))
     env.reset()
     act = torch.randint(0, 4, (n,), dtype=torch.uint8, device=env.device)
     ts = []
