@@ -238,7 +238,7 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
  *       where that form exists (at most two tiles per lane with 4 and 8 lanes; 8 lanes at least above 16x16).
  *   TS_TUNE_LINES_BPW  boards per wave of that kernel: 0 (default) = the policy (64 / lanes per board, fewer for
  *       boards whose observation is large: a wave's contiguous chunk of output should stay near 10 KB);
- *       1 .. 64 / lanes = forced (the remaining lanes idle).
+ *       1 .. 64 / lanes = forced (the remaining lanes idle; ignored where 12 * S * S * value is not a multiple of 16).
  *   TS_TUNE_EMIT_EDGES  launches beyond the Infinity Cache: bit 0 / bit 1 = the first / last store instruction of
  *       every wave's chunk of observation goes out as a write-back store instead of a nontemporal one; 4 (default) =
  *       the library's policy per kernel and shape.

@@ -1858,7 +1858,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_wave_bytes = align16(a.lds_oh_off) + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
     a.lds_oh_off = align16(a.lds_oh_off);
     a.bpw = (a.nt && TS_LINES_OOC_BPW > 0 && TS_LINES_OOC_BPW <= bpw_max) ? TS_LINES_OOC_BPW : (uint32_t)bpw_max;
-    if (const int64_t forced = g_lines_bpw.load(std::memory_order_relaxed); forced >= 1 && forced <= bpw_max) a.bpw = (uint32_t)forced;
+    // (a wave's chunk of float32 output must start on a 16-byte boundary: 12 * C * bpw % 16 == 0)
+    if (const int64_t forced = g_lines_bpw.load(std::memory_order_relaxed); forced >= 1 && forced <= bpw_max && (3 * C * forced) % 4 == 0) a.bpw = (uint32_t)forced;
     Residency res = ooc_residency(a.nt != 0, true, false,
                                         (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)), T);
     apply_launch_hint(res, d->launch_hint);
