@@ -52,6 +52,9 @@
 #ifndef TS_EMIT_ALIGN  // out-of-cache emit loop: store instructions cover whole 128-byte lines (see emit_bytes_as_f32)
 #define TS_EMIT_ALIGN 1
 #endif
+#ifndef TS_EMIT_ALIGN_CACHED  // the same for the agent-scope stores of cache-resident launches
+#define TS_EMIT_ALIGN_CACHED 1
+#endif
 #ifndef TS_EMIT_SHARED  // the pieces of a line that two waves share: 0 = nontemporal like the rest, 1 = plain (write-back), 2 = agent scope
 #define TS_EMIT_SHARED 1
 #endif
@@ -220,7 +223,7 @@ __device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
 // `dst` is 16-B aligned; img is 16-B aligned.  NT (nontemporal stores) is a template parameter in
 // k_small / k_lines: the cache-resident and the out-of-cache launch are different instantiations,
 // so a profile lists them as different kernels.
-template <bool NT>
+template <bool NT, bool ANY_START = false>
 __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane, uint32_t edges = 0) {
   const int nf4 = nfl >> 2;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
@@ -253,7 +256,7 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
       // in the store-only probe) even though the next instruction of the same wave completes the line.  Here instruction k
       // stores units 64 k + l - m: whole lines, except the first and last line of the chunk, which the neighbouring
       // waves share; those pieces go out as plain (write-back) stores, so that the two halves meet in the XCD's L2.
-      const int m = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u);
+      const int m = ANY_START ? (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u) : 0;  // k_small: chunks start on a line
       const int total = nf4 + m, iters = (total + kWave - 1) >> 6;
       const int last_line = total >> 3;
       const bool tail_shared = (total & 7) != 0;
@@ -285,7 +288,16 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
     } else {
       // the agent-scope store is an asm statement - a convergent operation to the compiler, which does not unroll a
       // loop around one with a run-time remainder; a hand-unrolled version measured the same (30.2 vs 30.2 us at cfg1)
-      for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+      if constexpr (ANY_START && TS_EMIT_ALIGN_CACHED) {
+        // whole-line store instructions for cache-resident launches of k_lines too, whose chunks start anywhere for odd
+        // board sizes (15x15 at 65,536 boards 29.2 -> 28.5 us, 11x11 29.1 -> 28.3); k_small / k_multi chunks always start
+        // on a line, and the extra lane test costs them 1 % (cfg1 30.07 -> 30.36), hence the template flag
+        const int m = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u);
+        for (int q = lane - m; q < nf4; q += kWave)
+          if (q >= 0) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+      } else {
+        for (int q = lane; q < nf4; q += kWave) store_f4<NT>(&d4[q], bytes_to_f4(w[q]));
+      }
     }
 #endif
   }
@@ -1292,7 +1304,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
       }
     }
     wave_sync();
-    if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+    if (a.obs) emit_bytes_as_f32<NT, true>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
     if (a.obs_u8) emit_bytes_raw<4, NT>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 
@@ -1331,7 +1343,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
         }
         wave_sync();
         const int64_t left = total - p0;
-        emit_bytes_as_f32<NT>(ohimg, dst + p0, (int)(left < kOhPiece ? left : kOhPiece), lane, a.emit_edges);
+        emit_bytes_as_f32<NT, true>(ohimg, dst + p0, (int)(left < kOhPiece ? left : kOhPiece), lane, a.emit_edges);
       }
     }
   }
