@@ -881,7 +881,8 @@ def test_placement_trials_leave_no_trace(torch_cuda, oracle):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("S,T,K,N,onehot", [(5, 2, 3, 1 << 20, True), (15, 32, 24, 1 << 18, False), (4, 2, 2, 1 << 22, False)])
+@pytest.mark.parametrize("S,T,K,N,onehot", [(5, 2, 3, 1 << 20, True), (15, 32, 24, 1 << 18, False), (4, 2, 2, 1 << 22, False),
+                                            (9, 4, 9, 1 << 19, False), (12, 8, 16, 1 << 18, True)])
 def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, onehot):
     """ts_dims.launch_hint moves the resident blocks per CU of launches beyond the Infinity Cache (k_small half
     waves, k_small + one-hot, k_lines): every value must give the buffers the library's own policy gives."""
@@ -889,8 +890,8 @@ def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, o
     from tiler_slider_amd import VecTilerSliderEnv
     kw = dict(size=S, num_tiles=T, num_obstacles=K, seed=5, multi_color=True, max_steps=6, auto_reset=True,
               with_reward=True, with_onehot=onehot)
-    ref = VecTilerSliderEnv.random(N, **kw)
-    env = VecTilerSliderEnv.random(N, **kw)
+    ref = VecTilerSliderEnv.random(N, placement_trials=0, **kw)
+    env = VecTilerSliderEnv.random(N, placement_trials=0, **kw)
     ref.reset(), env.reset()
     for step, hint in enumerate((-8, -3, -1, 1, 3, 8)):
         act = torch.from_numpy(oracle.fill_actions(N, seed=21, step_index=step))
@@ -901,6 +902,18 @@ def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, o
         assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(ref.positions, env.positions), hint
         if onehot:
             assert torch.equal(i1["onehot"], i2["onehot"]), hint
+    env._dims.launch_hint = 0
+    # the other per-call policy fields (ABI v4): which store instructions of a chunk are write-back, lanes per board
+    for step, (edges, lanes) in enumerate(((1, 0), (2, 4), (3, 8), (4, 16), (0, 4), (0, 8))):
+        act = torch.from_numpy(oracle.fill_actions(N, seed=22, step_index=step))
+        env._dims.emit_edges, env._dims.lines_lanes = edges, lanes
+        o1, d1, i1 = ref.step(act)
+        o2, d2, i2 = env.step(act)
+        assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(i1["flags"], i2["flags"]), (edges, lanes)
+        assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(ref.positions, env.positions), (edges, lanes)
+        if onehot:
+            assert torch.equal(i1["onehot"], i2["onehot"]), (edges, lanes)
+    env._dims.emit_edges, env._dims.lines_lanes = 0, 0
     env._dims.launch_hint = 9
     with pytest.raises(Exception):
         env.step(act)

@@ -52,6 +52,9 @@
 #ifndef TS_EMIT_ALIGN  // out-of-cache emit loop: store instructions cover whole 128-byte lines (see emit_bytes_as_f32)
 #define TS_EMIT_ALIGN 1
 #endif
+#ifndef TS_ANYT_OBS_BOARDS  // experiment: boards per observation pass of k_small's any-tile-count path from 6x6 on (0 = 32, as the register path)
+#define TS_ANYT_OBS_BOARDS 0
+#endif
 #ifndef TS_EMIT_ALIGN_CACHED  // the same for the agent-scope stores of cache-resident launches
 #define TS_EMIT_ALIGN_CACHED 1
 #endif
@@ -383,7 +386,14 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
 }
 
 // boards per observation pass of k_small (also used by the host to size the LDS carve)
-constexpr int small_obs_boards(int C) { return TS_FORCE_OBS_BOARDS ? TS_FORCE_OBS_BOARDS : (kWave * 3 * C <= 6144 ? kWave : kWave / 2); }
+// (Round 3 tried a smaller image for the any-tile-count path, whose long serial slide loop is latency-bound - 16 boards per
+// pass: 8x8 with 20 tiles 16 KB -> 5.5 KB of LDS per wave, 8 -> 28 waves per CU - for 97.2 -> 94.8 us there, 91.8 -> 86.5 with 12
+// tiles, but 82.0 -> 85.4 at 6x6 / 12 tiles and 38.7 -> 39.7 cache-resident: not shipped, TS_ANYT_OBS_BOARDS.)
+constexpr int small_obs_boards(int C, bool any_t = false) {
+  // (a pass must start on a 128-byte line of the output: 12 * C * boards % 128 == 0 - true for 6x6 and 8x8 with 16 boards)
+  return TS_FORCE_OBS_BOARDS ? TS_FORCE_OBS_BOARDS
+         : (kWave * 3 * C <= 6144 ? kWave : (any_t && TS_ANYT_OBS_BOARDS && (12 * C * TS_ANYT_OBS_BOARDS) % 128 == 0) ? TS_ANYT_OBS_BOARDS : kWave / 2);
+}
 
 constexpr int kSmallBatch = 8;  // global loads in flight per lane in the any-T tile / target loops
 
@@ -394,7 +404,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   using BB = ts::Bitboard<S>;
   using M = typename BB::mask_t;
   constexpr int C = BB::C;
-  constexpr int kObsBoards = small_obs_boards(C);
+  constexpr int kObsBoards = small_obs_boards(C, TFIX == 0);
   constexpr int kImg = kObsBoards * 3 * C;  // bytes, multiple of 16 (kObsBoards is 32 or 64)
   constexpr int TR = TFIX > 0 ? TFIX : 1;
 
@@ -438,12 +448,14 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   }
 #endif
   unsigned char *stage = img + a.lds_stage_off;
-  M *st_blk = reinterpret_cast<M *>(stage);  // [64] obstacles
+  unsigned char *st_np = stage;                                 // [T][64] post-move cells
+  unsigned char *st_tg = st_np + (size_t)T * kWave;             // [Tt][64] target cells
+  // the three masks exist only for the one-hot per-float fallback (very many planes): behind the cells
+  M *st_blk = reinterpret_cast<M *>(stage + (((size_t)(T + Tt) * kWave + 15) & ~(size_t)15));  // [64] obstacles
   M *st_occ = st_blk + kWave;                // [64] post-move tile mask
   M *st_tgm = st_occ + kWave;                // [64] target mask
-  unsigned char *st_np = stage + 3 * kWave * sizeof(uint64_t);  // [T][64] post-move cells
-  unsigned char *st_tg = st_np + (size_t)T * kWave;             // [Tt][64] target cells
-  const bool need_stage = (TFIX == 0) || (EXTRAS && a.onehot != nullptr && a.oh_boards == 0);
+  const bool need_masks = EXTRAS && a.onehot != nullptr && a.oh_boards == 0;
+  const bool need_stage = (TFIX == 0) || need_masks;
 
   // ---- loads: all unconditional, all issued before the first one is consumed ----
   // Lanes past the batch read the LAST board and write nothing.  (With `live ? load : default`
@@ -575,7 +587,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
     }
   }
-  if (need_stage) {
+  if (need_masks) {
     st_blk[lane] = blk;
     st_occ[lane] = occ2;
     st_tgm[lane] = tgm;
@@ -1816,9 +1828,10 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
       return finish_launch();
     }
 #endif
-    const bool need_stage = tfix == 0 || (a.onehot && !a.oh_boards);
-    a.lds_stage_off = align16((uint32_t)(small_obs_boards(C) * 3 * C));
-    a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(3 * kWave * 8 + kWave * (T + Tt))) : 0u);
+    const bool need_masks = a.onehot && !a.oh_boards;
+    const bool need_stage = tfix == 0 || need_masks;
+    a.lds_stage_off = align16((uint32_t)(small_obs_boards(C, tfix == 0) * 3 * C));
+    a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(kWave * (T + Tt))) + (need_masks ? 3u * kWave * 8u : 0u) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board);
