@@ -176,7 +176,7 @@ def main():
                          "launch policy, 1 = launch policy rated at construction on the first allocation (the class default), "
                          "k > 1 = also up to k candidate allocations of the output buffers (reported in config)")
     ap.add_argument("--policy", default=None,
-                    help="launch_hint,emit_edges,lines_lanes: fix the per-call launch policy of ts_dims (use with --placement-trials 0 "
+                    help="launch_hint,emit_edges,lines_lanes,xcd_piece: fix the per-call launch policy of ts_dims (use with --placement-trials 0 "
                          "to profile exactly the launches a tuned run settled on)")
     ap.add_argument("--output-memory", choices=["torch", "contiguous"], default="torch",
                     help="VecTilerSliderEnv(output_memory=...): physically contiguous output buffers beyond the Infinity Cache, or torch's allocator")
@@ -226,7 +226,7 @@ def main():
                                    device=device, auto_reset=True, with_reward=cfg["reward"],
                                    with_onehot=cfg["onehot"], placement_trials=args.placement_trials, output_memory=args.output_memory)
     if args.policy:
-        env._dims.launch_hint, env._dims.emit_edges, env._dims.lines_lanes = (int(x) for x in args.policy.split(","))
+        env._dims.launch_hint, env._dims.emit_edges, env._dims.lines_lanes, env._dims.xcd_piece = (int(x) for x in args.policy.split(","))
     env.reset()
     ring = []
     L = _cabi.lib()
@@ -417,7 +417,7 @@ def main():
                        # timed region; only for batches beyond the Infinity Cache): VecTilerSliderEnv docstring
                        "placement_trials": args.placement_trials, "placement": env.placement_report, "output_memory": args.output_memory,
                        "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges,
-                                         "lines_lanes": env._dims.lines_lanes},
+                                         "lines_lanes": env._dims.lines_lanes, "xcd_piece": env._dims.xcd_piece},
                        "parallelism": f"boards sharded over {world} GPU(s), no data-path collective",
                        "level_seed": hex(LEVEL_SEED), "action_seed": hex(ACTION_SEED)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -502,7 +502,7 @@ def time_config(name, trials, steps, device, L, stream):
         gbs = bps * n / us / 1e3
         out[key] = {"placement_trials": k, "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s", "achieved": gbs,
                     "achieved_unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS,
-                    "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges, "lines_lanes": env._dims.lines_lanes},
+                    "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges, "lines_lanes": env._dims.lines_lanes, "xcd_piece": env._dims.xcd_piece},
                     "placement": env.placement_report}
         del env
         torch.cuda.empty_cache()

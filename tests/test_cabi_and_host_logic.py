@@ -65,6 +65,8 @@ def test_argument_validation_precedes_any_launch():
     for edges, lanes, want in ((0, 0, _cabi.OK), (4, 16, _cabi.OK), (1, 4, _cabi.OK), (3, 8, _cabi.OK), (5, 0, _cabi.ERR_DIMS), (-1, 0, _cabi.ERR_DIMS),
                                (0, 2, _cabi.ERR_DIMS), (0, 32, _cabi.ERR_DIMS), (0, -4, _cabi.ERR_DIMS)):
         assert L.ts_check_dims(C.byref(_cabi.Dims(8, 12, 2, 2, 0, 100, 0, edges, lanes))) == want, (edges, lanes)
+    for piece, want in ((0, _cabi.OK), (1, _cabi.OK), (64, _cabi.OK), (-1, _cabi.ERR_DIMS), ((1 << 20) + 1, _cabi.ERR_DIMS)):
+        assert L.ts_check_dims(C.byref(_cabi.Dims(8, 12, 2, 2, 0, 100, 0, 0, 0, piece))) == want, piece
     for bad, want in ():
         assert L.ts_check_dims(C.byref(bad)) == want
     st, out = _cabi.State(), _cabi.StepOut()

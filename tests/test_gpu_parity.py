@@ -862,7 +862,8 @@ def test_placement_trials_leave_no_trace(torch_cuda, oracle):
         tuned = VecTilerSliderEnv.random(N, auto_reset=autoreset, placement_trials=3, obs_buffers=2, **kw)
         rep = tuned.placement_report
         pol = rep["policy"][rep["chosen"]]
-        assert (tuned._dims.launch_hint, tuned._dims.emit_edges, tuned._dims.lines_lanes) == (pol["launch_hint"], pol["emit_edges"], pol["lines_lanes"])
+        assert (tuned._dims.launch_hint, tuned._dims.emit_edges, tuned._dims.lines_lanes, tuned._dims.xcd_piece) == \
+            (pol["launch_hint"], pol["emit_edges"], pol["lines_lanes"], pol["xcd_piece"])
         assert rep["us_per_step"][rep["chosen"]] <= rep["library_policy_us"][rep["chosen"]]
         assert 1 <= rep["trials"] <= 3 and len(rep["us_per_step"]) == rep["trials"] and 0 <= rep["chosen"] < rep["trials"]
         assert rep["us_per_step"][rep["chosen"]] == min(rep["us_per_step"])
@@ -904,16 +905,16 @@ def test_launch_hint_changes_speed_not_results(torch_cuda, oracle, S, T, K, N, o
             assert torch.equal(i1["onehot"], i2["onehot"]), hint
     env._dims.launch_hint = 0
     # the other per-call policy fields (ABI v4): which store instructions of a chunk are write-back, lanes per board
-    for step, (edges, lanes) in enumerate(((1, 0), (2, 4), (3, 8), (4, 16), (0, 4), (0, 8))):
+    for step, (edges, lanes, piece) in enumerate(((1, 0, 0), (2, 4, 1), (3, 8, 2), (4, 16, 64), (0, 4, 7), (0, 8, 1000))):
         act = torch.from_numpy(oracle.fill_actions(N, seed=22, step_index=step))
-        env._dims.emit_edges, env._dims.lines_lanes = edges, lanes
+        env._dims.emit_edges, env._dims.lines_lanes, env._dims.xcd_piece = edges, lanes, piece
         o1, d1, i1 = ref.step(act)
         o2, d2, i2 = env.step(act)
         assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(i1["flags"], i2["flags"]), (edges, lanes)
         assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(ref.positions, env.positions), (edges, lanes)
         if onehot:
             assert torch.equal(i1["onehot"], i2["onehot"]), (edges, lanes)
-    env._dims.emit_edges, env._dims.lines_lanes = 0, 0
+    env._dims.emit_edges, env._dims.lines_lanes, env._dims.xcd_piece = 0, 0, 0
     env._dims.launch_hint = 9
     with pytest.raises(Exception):
         env.step(act)

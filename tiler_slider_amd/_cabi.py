@@ -20,7 +20,7 @@ OK, ERR_NULL, ERR_DIMS, ERR_LIMIT, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0x08
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
 MODE_STRICT, MODE_AUTORESET = 0, 1
-TUNE_MULTI_MIN_BOARDS, TUNE_NT_THRESHOLD_BYTES, TUNE_LINES_LANES, TUNE_LINES_BPW, TUNE_EMIT_EDGES = 0, 1, 2, 3, 4
+TUNE_MULTI_MIN_BOARDS, TUNE_NT_THRESHOLD_BYTES, TUNE_LINES_LANES, TUNE_LINES_BPW, TUNE_EMIT_EDGES, TUNE_XCD_PIECE = 0, 1, 2, 3, 4, 5
 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
@@ -31,7 +31,7 @@ EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error
 class Dims(C.Structure):
     _fields_ = [("n_boards", C.c_int64), ("size", C.c_int32), ("n_tiles", C.c_int32), ("n_targets", C.c_int32),
                 ("multi_color", C.c_int32), ("max_steps", C.c_int32), ("launch_hint", C.c_int32), ("emit_edges", C.c_int32),
-                ("lines_lanes", C.c_int32)]
+                ("lines_lanes", C.c_int32), ("xcd_piece", C.c_int32)]
 
 
 class State(C.Structure):

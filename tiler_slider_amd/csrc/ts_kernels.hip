@@ -83,7 +83,10 @@
 #ifndef TS_XCD_REMAP
 #define TS_XCD_REMAP 1
 #endif
-#ifndef TS_XCD_PIECE  // 0 = each XCD owns one contiguous eighth of the batch; P > 0 = pieces of P blocks, round-robin
+#ifndef TS_XCD_PIECE_POLICY  // out-of-cache launches with short chunks per wave: pieces of P blocks per XCD (piece_policy)
+#define TS_XCD_PIECE_POLICY 64
+#endif
+#ifndef TS_XCD_PIECE  // experiment (all launches, compile time): 0 = as the policy; P > 0 = pieces of P blocks, round-robin
 #define TS_XCD_PIECE 0
 #endif
 #ifndef TS_MULTI_G  // boards per lane of k_multi (2 or 4); 0 = never launch it
@@ -160,6 +163,7 @@ struct KArgs {
   uint32_t oh_boards;   // one-hot byte image: boards per chunk (0 = evaluate per float)
   uint32_t lds_oh_off;  // offset of that image inside the wave's carve
   uint32_t bpw;         // boards per wave (k_small: 64, k_lines: 4; fewer beyond the Infinity Cache)
+  uint32_t xcd_piece;   // block -> board-range mapping (xcd_contiguous_block): 0 = one contiguous eighth per XCD, P = pieces of P blocks
   uint32_t emit_edges;  // out-of-cache launches: bit 0 / 1 = first / last store instruction of a wave's chunk as write-back stores
 };
 
@@ -372,16 +376,19 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 //   * k_lines: a wave touches just 4 consecutive bytes of each SoA state row, so in blockIdx
 //     order every 128-B line of pos/tgt/blk would be read and partially written through all 8
 //     non-coherent L2s.
-__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks) {
-#if TS_XCD_REMAP && TS_XCD_PIECE > 0
-  // pieces of TS_XCD_PIECE consecutive blocks per XCD, dealt round-robin: the eight write fronts
-  // stay within 8 * TS_XCD_PIECE blocks of each other
-  constexpr uint32_t P = TS_XCD_PIECE;
-  const uint32_t full = nblocks / (8u * P) * (8u * P);
-  if (bid >= full) return bid;
-  const uint32_t xcd = bid & 7u, k = bid >> 3;
-  return ((k / P) * 8u + xcd) * P + (k % P);
-#elif TS_XCD_REMAP
+// `piece` (KArgs.xcd_piece, round 3): 0 = each XCD owns one contiguous eighth of the batch; P > 0 = pieces of P consecutive
+// blocks per XCD, dealt round-robin over the eight XCDs, so that the eight write fronts stay within 8 * P blocks of each other.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks, uint32_t piece = 0) {
+#if TS_XCD_REMAP
+#if TS_XCD_PIECE > 0
+  piece = TS_XCD_PIECE;
+#endif
+  if (piece > 0) {
+    const uint32_t full = nblocks / (8u * piece) * (8u * piece);
+    if (bid >= full) return bid;
+    const uint32_t xcd = bid & 7u, k = bid >> 3;
+    return ((k / piece) * 8u + xcd) * piece + (k % piece);
+  }
   const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 #else
@@ -418,7 +425,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   // a.bpw boards per wave: 64 (one per lane), or fewer for launches beyond the Infinity Cache (the
   // upper lanes idle; a wave's contiguous chunk of output shrinks accordingly)
   const int bpw = (int)a.bpw;
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * bpw;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform; no block-level barrier exists in this kernel
   const int64_t N = a.N;
   const int64_t n = n0 + lane;
@@ -1047,7 +1054,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   const int wave = threadIdx.x >> 6;
   const int g = lane / G, j = lane & (G - 1);
   const int bpw = (int)a.bpw;  // boards per wave: 64 / LPB (or fewer: the upper lanes idle)
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wave) * bpw;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform
   const int64_t N = a.N;
   const int64_t n = n0 + g;
@@ -1565,12 +1572,13 @@ thread_local int32_t t_last_hip_error = 0;
 std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_TUNE_MULTI_MIN_BOARDS)
 std::atomic<int64_t> g_lines_lanes{0};  // ts_tuning(TS_TUNE_LINES_LANES): 0 = by tile count, 4 / 8 / 16 = forced where instantiated
 std::atomic<int64_t> g_lines_bpw{0};    // ts_tuning(TS_TUNE_LINES_BPW): 0 = policy, else boards per wave of k_lines (the other lanes idle)
+std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): INT64_MAX = policy, 0 = eighths, P = pieces of P blocks (out-of-cache launches)
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
 std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
 
 int32_t check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
-  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 || d->emit_edges < 0 || d->emit_edges > 4 ||
+  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 || d->emit_edges < 0 || d->emit_edges > 4 || d->xcd_piece < 0 || d->xcd_piece > (1 << 20) ||
       (d->lines_lanes != 0 && d->lines_lanes != 4 && d->lines_lanes != 8 && d->lines_lanes != 16) ||
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;
@@ -1746,6 +1754,16 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
 // wave has six store instructions: 115 -> 194 us with two of them write-back).  profiles/r03_emit_edges_ab.log
 uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= 8u * 1024u ? 3u : 0u; }
 
+// Block -> board-range mapping of out-of-cache launches (KArgs.xcd_piece, xcd_contiguous_block).  One contiguous eighth of
+// the batch per XCD is the best mapping on a "fast" allocation of the output buffers and among the worst on a "slow" one (the
+// 4x4 launch at 4M boards: 116.7 us fast, 129 slow); pieces of 64 one-wave blocks per XCD, dealt round-robin, keep the eight
+// write fronts within a few MB of each other and gave 121.5 us on every allocation of that launch - and 118 against 137-140 on
+// another box (profiles/r03_xcd_piece_ab.log).  For longer chunks the picture changes from box to box (cfg2 with pieces of 64:
+// 133 -> 125 us on one box, 132 -> 139 on the next, where 32 gave 124; 7x7 / 20x20 and up lose 15-25 % with 64 on that box), so
+// the static policy uses pieces only for short chunks and the per-environment rating (VecTilerSliderEnv placement_trials)
+// tries 32 / 64 / 128 / eighths on the buffers it has.
+uint32_t piece_policy(uint64_t chunk) { return chunk < 8u * 1024u ? TS_XCD_PIECE_POLICY : 0u; }
+
 // Boards per wave of k_small.  Beyond the Infinity Cache the register-path kernels run HALF waves —
 // 32 boards, the upper lanes idle — once a full wave would write 8 KB or more: the transition
 // arithmetic is a small part of such a launch (7.6 of 33 us at cfg1), while halving every wave's
@@ -1802,6 +1820,9 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.nt = per_board * (uint64_t)d->n_boards > (uint64_t)g_nt_threshold_bytes.load(std::memory_order_relaxed) ? 1u : 0u;
   }
   if (a.nt) {
+    const int64_t piece = g_xcd_piece.load(std::memory_order_relaxed);
+    a.xcd_piece = d->xcd_piece == 1 ? 0u : d->xcd_piece > 1 ? (uint32_t)d->xcd_piece
+                  : piece <= 0x7fffffff ? (uint32_t)piece : 0xffffffffu;  // 0xffffffff: by kernel, below
     const int64_t forced = g_emit_edges.load(std::memory_order_relaxed);
     a.emit_edges = d->emit_edges > 0 ? (uint32_t)(d->emit_edges - 1) : forced >= 0 && forced <= 3 ? (uint32_t)forced : 0xffu;  // 0xff: by shape, below
   }
@@ -1888,6 +1909,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                                         (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)), T);
     apply_launch_hint(res, d->launch_hint);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
+    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = 0u;  // k_lines: see piece_policy
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
@@ -2088,7 +2110,8 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_NT_THRESHOLD_BYTES ? &g_nt_threshold_bytes
                                : key == TS_TUNE_LINES_LANES ? &g_lines_lanes
                                : key == TS_TUNE_LINES_BPW ? &g_lines_bpw
-                               : key == TS_TUNE_EMIT_EDGES ? &g_emit_edges : nullptr;
+                               : key == TS_TUNE_EMIT_EDGES ? &g_emit_edges
+                               : key == TS_TUNE_XCD_PIECE ? &g_xcd_piece : nullptr;
   if (!knob) return -1;
   return value >= 0 ? knob->exchange(value) : knob->load();
 }

@@ -320,7 +320,7 @@ class VecTilerSliderEnv:
         def rate(policy):
             """us per step with ts_dims policy fields (launch_hint, emit_edges, lines_lanes); a set of buffers counts as its
             slowest member."""
-            d.launch_hint, d.emit_edges, d.lines_lanes = policy
+            d.launch_hint, d.emit_edges, d.lines_lanes, d.xcd_piece = policy
             worst = 0.0
             for out in self._outs:
                 for i in range(3):
@@ -334,8 +334,8 @@ class VecTilerSliderEnv:
             return worst
 
         def search():
-            """Coordinate search from the library's own policy (0, 0, 0): resident blocks per CU, then the edge stores, then
-            (boards above 8x8) the lanes per board, then one refinement of the first."""
+            """Coordinate search from the library's own policy (all fields 0): resident blocks per CU, then the edge stores, then
+            (boards above 8x8) the lanes per board, then the block -> board-range mapping, then one refinement of the first."""
             seen = {}
 
             def best_of(cands):
@@ -344,12 +344,13 @@ class VecTilerSliderEnv:
                         seen[c] = rate(c)
                 return min(cands, key=seen.__getitem__)
 
-            cur = best_of([(h, 0, 0) for h in (0, -2, 2, 4, 8)])
-            cur = best_of([cur] + [(cur[0], e, 0) for e in (1, 4)])
+            cur = best_of([(h, 0, 0, 0) for h in (0, -2, 2, 4, 8)])
+            cur = best_of([cur] + [(cur[0], e, 0, 0) for e in (1, 4)])
             if self.size > 8:
-                cur = best_of([cur] + [(cur[0], cur[1], ln) for ln in (4, 8, 16)])
-            cur = best_of([cur] + [(cur[0] + dh, cur[1], cur[2]) for dh in (-1, 1, 2) if -8 <= cur[0] + dh <= 8])
-            return cur, seen[cur], seen[(0, 0, 0)]
+                cur = best_of([cur] + [(cur[0], cur[1], ln, 0) for ln in (4, 8, 16)])
+            cur = best_of([cur] + [cur[:3] + (pc,) for pc in (1, 32, 64, 128)])  # 1 = one eighth of the batch per XCD
+            cur = best_of([cur] + [(cur[0] + dh,) + cur[1:] for dh in (-1, 1, 2) if -8 <= cur[0] + dh <= 8])
+            return cur, seen[cur], seen[(0, 0, 0, 0)]
 
         with torch.cuda.device(self.device):
             for k in range(trials):
@@ -375,9 +376,9 @@ class VecTilerSliderEnv:
             if t is not None:
                 t.zero_()
         self._bind_outputs()
-        d.launch_hint, d.emit_edges, d.lines_lanes = policies[best]
+        d.launch_hint, d.emit_edges, d.lines_lanes, d.xcd_piece = policies[best]
         self.placement_report = {"us_per_step": [round(t, 2) for t in times], "library_policy_us": [round(t, 2) for t in policy_us],
-                                 "policy": [{"launch_hint": p[0], "emit_edges": p[1], "lines_lanes": p[2]} for p in policies],
+                                 "policy": [{"launch_hint": p[0], "emit_edges": p[1], "lines_lanes": p[2], "xcd_piece": p[3]} for p in policies],
                                  "launch_hint": [p[0] for p in policies], "chosen": best, "trials": len(times)}
 
     # buffers live on the GPU, or (host_mapped) in pinned host memory the GPU addresses directly

@@ -20,12 +20,17 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(64) void k_chunks(f32x4 *dst, int64_t total16, int chunk16, int mode) {
+__global__ __launch_bounds__(64) void k_chunks(f32x4 *dst, int64_t total16, int chunk16, int mode, int piece) {
   extern __shared__ unsigned char smem[];  // only to bound the resident blocks per CU
   const int lane = threadIdx.x;
   uint32_t bid = blockIdx.x;
   const uint32_t nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = bid & 7u;
-  bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);  // XCD-contiguous, as the product kernels
+  if (piece > 0) {  // pieces of `piece` consecutive chunks per XCD, dealt round-robin over the 8 XCDs
+    const uint32_t P = (uint32_t)piece, full = nb / (8u * P) * (8u * P);
+    if (bid < full) bid = (((bid >> 3) / P) * 8u + x) * P + ((bid >> 3) % P);
+  } else if (piece == 0) {
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);  // XCD-contiguous, as the product kernels
+  }  // piece < 0: blockIdx order
   int64_t a = (int64_t)bid * chunk16, b = a + chunk16;
   if (mode == 2) {
     a &= ~7ll;
@@ -60,10 +65,14 @@ __global__ __launch_bounds__(64) void k_chunks(f32x4 *dst, int64_t total16, int 
   }
 }
 
+extern "C" int ap_fill2(void *dst, int64_t nbytes, int chunk_bytes, int mode, int lds_bytes, int piece, void *stream);
 extern "C" int ap_fill(void *dst, int64_t nbytes, int chunk_bytes, int mode, int lds_bytes, void *stream) {
+  return ap_fill2(dst, nbytes, chunk_bytes, mode, lds_bytes, 0, stream);
+}
+extern "C" int ap_fill2(void *dst, int64_t nbytes, int chunk_bytes, int mode, int lds_bytes, int piece, void *stream) {
   const int64_t total16 = nbytes / 16;
   const int chunk16 = chunk_bytes / 16;
   const int64_t blocks = (total16 + chunk16 - 1) / chunk16;
-  hipLaunchKernelGGL(k_chunks, dim3((uint32_t)blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (f32x4 *)dst, total16, chunk16, mode);
+  hipLaunchKernelGGL(k_chunks, dim3((uint32_t)blocks), dim3(64), (size_t)lds_bytes, (hipStream_t)stream, (f32x4 *)dst, total16, chunk16, mode, piece);
   return (int)hipGetLastError();
 }

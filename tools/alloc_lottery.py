@@ -50,6 +50,37 @@ def show(tag, ptr):
 
 
 hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+if len(sys.argv) > 1 and sys.argv[1] == "pieces":
+    # does some block -> address mapping make a physically contiguous buffer (where the mapping's physical offsets are the
+    # virtual ones) as fast as a lucky ordinary allocation?  pieces of P chunks per XCD round-robin; 0 = one eighth each
+    L.ap_fill2.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+
+    def rate2(ptr, piece, chunk=10752):
+        ts = []
+        for r in range(3):
+            for i in range(2):
+                L.ap_fill2(ptr, NB, chunk, 0, LDS10, piece, st)
+            e0.record()
+            for i in range(10):
+                L.ap_fill2(ptr, NB, chunk, 0, LDS10, piece, st)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 10)
+        return NB / statistics.median(ts) / 1e9
+
+    bufs = []
+    p = C.c_void_p()
+    assert hip.hipExtMallocWithFlags(C.byref(p), NB, 4) == 0
+    bufs.append(("contiguous", p.value))
+    for i in range(3):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), NB) == 0
+        bufs.append((f"hipMalloc #{i}", p.value))
+    pieces = (-1, 0, 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096)
+    print("TB/s by XCD piece (chunks of 10.5 KiB; -1 = blockIdx order, 0 = one contiguous eighth per XCD):", pieces)
+    for tag, ptr in bufs:
+        print(f"  {tag:14s}", " ".join(f"{rate2(ptr, pc):5.2f}" for pc in pieces), flush=True)
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "contiguous":
     # hipDeviceMallocContiguous (0x4): physically contiguous device memory
     for rnd in range(2):
