@@ -383,7 +383,7 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
 #if TS_XCD_PIECE > 0
   piece = TS_XCD_PIECE;
 #endif
-  if (piece > 0) {
+  if (piece > 0 && piece < (1u << 24)) {
     const uint32_t full = nblocks / (8u * piece) * (8u * piece);
     if (bid >= full) return bid;
     const uint32_t xcd = bid & 7u, k = bid >> 3;
@@ -1857,6 +1857,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board);
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
+    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy((uint64_t)a.bpw * out_per_board);
     apply_launch_hint(res, d->launch_hint);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;

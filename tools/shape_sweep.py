@@ -17,18 +17,26 @@ for S, T, K in SHAPES:
                                    auto_reset=True, placement_trials=int(os.environ.get('TS_SWEEP_TRIALS', '0')))
     env.reset()
     act = torch.randint(0, 4, (n,), dtype=torch.uint8, device=env.device)
-    ts = []
-    for r in range(4):
-        for i in range(3):
-            env.step_async(act)
-        e0.record()
-        for i in range(20):
-            env.step_async(act)
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / 20 * 1e3)
-    us = statistics.median(ts)
+    def timed():
+        ts = []
+        for r in range(4):
+            for i in range(3):
+                env.step_async(act)
+            e0.record()
+            for i in range(20):
+                env.step_async(act)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 20 * 1e3)
+        return statistics.median(ts)
+
+    us = timed()
+    extra = ""
+    for piece in [int(x) for x in os.environ.get("TS_SWEEP_PIECES", "").split(",") if x]:  # the same buffers with another block mapping
+        env._dims.xcd_piece = piece
+        extra += f"   piece {piece}: {timed():7.1f}"
+    env._dims.xcd_piece = 0
     bps = bench.algorithmic_bytes_per_board_step(S, T, False, False) + (T * 2 if S > 16 else 0) * 1  # 16-bit cells above 16x16
     gbs = bps * n / us / 1e3
-    print(f"{S:4d} {T:4d} {K:4d} {n:9d} {12 * S * S * n / 1e6:8.0f} {us:10.1f} {n / us * 1e6:10.3e} {gbs:10.0f} {gbs / 80:10.1f}", flush=True)
+    print(f"{S:4d} {T:4d} {K:4d} {n:9d} {12 * S * S * n / 1e6:8.0f} {us:10.1f} {n / us * 1e6:10.3e} {gbs:10.0f} {gbs / 80:10.1f}{extra}", flush=True)
     del env
