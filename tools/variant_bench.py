@@ -59,10 +59,10 @@ def run(a):
     for _ in range(a.placement + 1):  # the step time depends on where the buffers landed (tools/placement_study.py)
         env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
                                        seed=bench.LEVEL_SEED, multi_color=True, max_steps=2**30, device=dev,
-                                       auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"])
+                                       auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"], placement_trials=0)
         keep.append(env)
     env.reset()
-    env._dims.launch_hint = a.hint
+    env._dims.launch_hint, env._dims.xcd_piece, env._dims.emit_edges = a.hint, a.piece, a.edges
     stream = torch.cuda.current_stream(dev).cuda_stream
     ring = []
     for i in range(16):
@@ -132,7 +132,7 @@ def run(a):
                 times[name].append(e0.elapsed_time(e1) * 1e3 / a.steps)
     bps = bench.algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
     res = {}
-    print(f"{a.config}: {n} boards, {bps} B/board-step, {a.rounds} rounds x {a.steps} steps, launch_hint {a.hint}")
+    print(f"{a.config}: {n} boards, {bps} B/board-step, {a.rounds} rounds x {a.steps} steps, launch_hint {a.hint}, xcd_piece {a.piece}, emit_edges {a.edges}")
     for name in names:
         med, mn = statistics.median(times[name]), min(times[name])
         res[name] = {"flags": manifest[name], "median_us": med, "min_us": mn, "GBps_median": bps * n / med / 1e3}
@@ -155,6 +155,8 @@ if __name__ == "__main__":
     r.add_argument("--shape", help="S,T,K,N: ad-hoc shape registered under --config's name")
     r.add_argument("--no-check", action="store_true")
     r.add_argument("--hint", type=int, default=0, help="ts_dims.launch_hint for every variant")
+    r.add_argument("--piece", type=int, default=0, help="ts_dims.xcd_piece for every variant")
+    r.add_argument("--edges", type=int, default=0, help="ts_dims.emit_edges for every variant")
     r.add_argument("--tag", default="")
     r.add_argument("--placement", type=int, default=0, help="use the K-th allocation of the environment")
     r.add_argument("--pick", choices=["slowest", "fastest"], help="with --placement K: rate the K+1 allocations, use that one")
