@@ -1769,10 +1769,14 @@ uint32_t piece_policy(uint64_t chunk) { return chunk < 8u * 1024u ? TS_XCD_PIECE
 // arithmetic is a small part of such a launch (7.6 of 33 us at cfg1), while halving every wave's
 // chunk of output at the same bytes in flight per CU is worth 3-12 % (4x4 at 4M boards 126 -> 113 us,
 // cfg2 132 -> 121, 6x6 77 -> 68; profiles/r02_ooc_residency_sweep.log).
-int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t chunk_full_wave) {
+int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t chunk_full_wave, uint64_t state_bytes) {
 #if TS_SMALL_OOC_BPW > 0
   return (out_of_cache && register_path) ? TS_SMALL_OOC_BPW : kWave;
 #else
+  // Once the STATE of the batch no longer fits the Infinity Cache either (tens of millions of boards) a half wave's 32-byte
+  // pieces of every state row cost more than its shorter chunk wins: 4x4 at 64M boards 3.35 ms with half waves, 2.57 with full
+  // ones (at 16M boards, 300 MB of state, half waves still win: 592 vs 722 us).
+  if (state_bytes > (640ull << 20)) return kWave;
   return (out_of_cache && register_path && chunk_full_wave >= 8u * 1024u && TS_OOC_WAVES != 0) ? 32 : kWave;
 #endif
 }
@@ -1854,7 +1858,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(kWave * (T + Tt))) + (need_masks ? 3u * kWave * 8u : 0u) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
-    a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board);
+    a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board,
+                                            (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7));
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
     if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy((uint64_t)a.bpw * out_per_board);
