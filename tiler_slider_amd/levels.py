@@ -13,28 +13,140 @@ MAX_SIZE = 32
 MAX_TILES = 255
 
 
-class ImageLoader:
-    """The level record of the reference's screenshot loader, without the loader.
+def in_range_mask(image, lo, hi):
+    """OpenCV's `inRange` for a channel-last image: 255 where EVERY channel lies in [lo, hi] (both inclusive), else 0.
+    Bounds below 0 / above 255 behave as OpenCV's saturated ones do (uint8 pixels are compared against the bounds clipped
+    to the pixel range; an interval that misses the range entirely matches nothing)."""
+    px = np.asarray(image)
+    lo, hi = np.asarray(lo, dtype=np.int64), np.asarray(hi, dtype=np.int64)
+    if px.dtype != np.uint8:
+        inside = (px >= lo) & (px <= hi)
+    else:
+        inside = (px >= np.clip(lo, 0, 255).astype(np.uint8)) & (px <= np.clip(hi, 0, 255).astype(np.uint8)) & ((lo <= 255) & (hi >= 0))
+    # (a reduction over a last axis of 3 is numpy's slow path: AND the channel planes instead)
+    return np.logical_and.reduce([inside[..., k] for k in range(inside.shape[-1])]).astype(np.uint8) * 255
 
-    ref: explainrl/environment/dataloader.py:21-27.  `ImageProcessed` is the level schema every
-    environment constructor consumes (environment.py:61-80), kept under the reference's name so
-    that `TilerSliderEnv.from_level(ImageLoader.ImageProcessed(...))` reads as it does there.
-    Parsing the 400 phone screenshots (dataloader.py:29-133) needs OpenCV and is outside the
-    hot path; nothing else of that module is reproduced here.
+
+def _line_groups(marks, min_gap=25):
+    """Cell extents between separator lines: for consecutive marked indices further than `min_gap` apart, the open run
+    between them (dataloader.py:56-61)."""
+    return [(int(marks[k - 1]) + 1, int(marks[k])) for k in range(1, len(marks)) if marks[k] > marks[k - 1] + min_gap]
+
+
+class ImageLoader:
+    """The reference's screenshot loader: level records from phone screenshots of the game.
+
+    ref: explainrl/environment/dataloader.py:8-133.  `ImageProcessed` is the level schema every environment constructor
+    consumes (environment.py:61-80).  `parse_puzzle_image` is the reference's procedure restated on NumPy alone: its only
+    OpenCV call is `cv.inRange` (dataloader.py:46-50, 72-78, 81-87, 94-100), which is `in_range_mask` above.  Host-side and
+    offline (levels are parsed once, long before the hot path runs).
+
+    **Parity unpinned**: the reference cannot run its own parser here (cv2 is absent) and its tests hold no parsed level
+    (tests/test_dataloader.py checks the dataclasses and constants only), so no reference output exists to compare with.
+    What is checked instead: the reference's own asserts hold on all 400 screenshots of its data/ directory, sizes and
+    counts are plausible, and every parsed level replays HIP == oracle (tests/test_levels_from_screenshots.py).
     """
 
+    BACKGROUND_COLOR = np.array([0, 172, 194])      # dataloader.py:10-12
+    EMPTY_TILE_COLOR = np.array([223, 247, 249])
+    COLOR_TOLERANCE = np.array([10, 10, 10])
+
     @dataclass
-    class ImageProcessed:
+    class ImageRawData:                              # dataloader.py:14-19
+        name: str
+        puzzle_image: np.ndarray
+        level_label: np.ndarray
+        target_moves: np.ndarray
+
+    @dataclass
+    class ImageProcessed:                            # dataloader.py:21-27
         size: int
         blocked_locations: list
         initial_locations: list
         target_locations: list
         multiple_colors: bool = False
 
+    def __init__(self, directory=None):
+        """The .jpg files of `directory`, sorted (the reference lists the current working directory: dataloader.py:29-30,
+        which is what directory=None does)."""
+        import os
+        self.directory = directory
+        self.files = [f for f in sorted(os.listdir(directory)) if f.endswith(".jpg")]
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, image_id):
+        """Crops of one 1080 x 2340 screenshot (dataloader.py:35-42): the board, the level label, the move counter."""
+        import os
+        from matplotlib import pyplot as plt  # what the reference decodes with (dataloader.py:36)
+        name = self.files[image_id]
+        image = plt.imread(name if self.directory is None else os.path.join(self.directory, name))
+        return self.ImageRawData(name=name, puzzle_image=image[665:1710, 15:-15], level_label=image[420:500, 25:500],
+                                 target_moves=image[570:650, 600:1000])
+
+    @classmethod
+    def _is_empty_colour(cls, patch):
+        return bool(np.all(in_range_mask(patch, cls.EMPTY_TILE_COLOR - cls.COLOR_TOLERANCE, cls.EMPTY_TILE_COLOR + cls.COLOR_TOLERANCE)))
+
     @classmethod
     def parse_puzzle_image(cls, target_image, multiple_colors):
-        raise NotImplementedError("screenshot parsing needs OpenCV (absent) and is outside the hot path; "
-                                  "build levels with ImageLoader.ImageProcessed(...) or the factory")
+        """Board crop -> ImageProcessed (ref: dataloader.py:44-133).
+
+        Separator lines are the rows / columns whose mean background-colour mask exceeds 100; cells are the gaps wider
+        than 25 px between them.  Each cell, shrunk by a tenth of its height on every side, is classified in the
+        reference's order: all empty colour -> free; centre empty -> a tile (a ring; its colour = mean of the top-left
+        fifth); top-left fifth empty -> a goal (a dot; colour = mean of the centre); else an obstacle.  With
+        `multiple_colors` tile i is the one tile whose colour is within |tolerance| of goal i's."""
+        target_image = np.asarray(target_image)
+        boundary = in_range_mask(target_image, cls.BACKGROUND_COLOR - cls.COLOR_TOLERANCE, cls.BACKGROUND_COLOR + cls.COLOR_TOLERANCE)
+        r_lines, = np.where(boundary.mean(axis=1) > 100.0)
+        c_lines, = np.where(boundary.mean(axis=0) > 100.0)
+        # dataloader.py:53-54 writes `[1,] + r_lines` with r_lines an ndarray: that is an element-wise + 1 (broadcast),
+        # NOT a list prepend - every line index moves down by one and no line "1" is added.  Kept as is: a prepend would
+        # add a group in front of the first separator.
+        r_lines = r_lines + 1
+        c_lines = c_lines + 1
+        c_groups, r_groups = _line_groups(c_lines), _line_groups(r_lines)
+
+        blocked, tiles, goals = [], [], []  # tiles / goals: ((r, c), mean colour)
+        for r, (r0, r1) in enumerate(r_groups):
+            for c, (c0, c1) in enumerate(c_groups):
+                cell = target_image[r0:r1, c0:c1]
+                m = int(0.1 * len(cell))
+                cell = cell[m:-m, m:-m]   # (the reference trims both axes by a tenth of the HEIGHT: dataloader.py:69-70)
+                h = len(cell)
+                centre = cell[int(0.45 * h):int(0.55 * h), int(0.45 * h):int(0.55 * h)]
+                corner = cell[int(0.0 * h):int(0.2 * h), int(0.0 * h):int(0.2 * h)]
+                if cls._is_empty_colour(cell):
+                    continue
+                if cls._is_empty_colour(centre):
+                    tiles.append(((r, c), np.mean(corner, axis=(0, 1))))
+                elif cls._is_empty_colour(corner):
+                    goals.append(((r, c), np.mean(centre, axis=(0, 1))))
+                else:
+                    blocked.append((r, c))
+
+        assert len(r_groups) == len(c_groups), "Board should always be a square"       # dataloader.py:106
+        assert len(goals) == len(tiles), "Each tile should have a goal"                # dataloader.py:107
+
+        if multiple_colors:
+            limit = np.linalg.norm(cls.COLOR_TOLERANCE)
+            tile_cells, goal_cells = [], []
+            for goal_cell, goal_colour in goals:
+                match = [k for k, (_, colour) in enumerate(tiles) if np.linalg.norm(goal_colour - colour) < limit]
+                assert len(match) == 1, "Exactly one tile should want to come to this goal"  # dataloader.py:118
+                tile_cells.append(tiles[match[0]][0])
+                goal_cells.append(goal_cell)
+        else:
+            tile_cells, goal_cells = [cell for cell, _ in tiles], [cell for cell, _ in goals]
+        return cls.ImageProcessed(size=len(r_groups), blocked_locations=blocked, initial_locations=tile_cells,
+                                  target_locations=goal_cells, multiple_colors=multiple_colors)
+
+    def parse(self, image_id):
+        """Level of screenshot `image_id`; the colour mode is in the file name (puzzle_multi_*.jpg / puzzle_single_*.jpg)."""
+        raw = self[image_id]
+        return self.parse_puzzle_image(raw.puzzle_image, multiple_colors="multi" in raw.name)
 
 
 Level = ImageLoader.ImageProcessed  # the level record, under a shorter name
