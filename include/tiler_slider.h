@@ -37,6 +37,7 @@
  *    onehot     float32[N][Ch][S][S]    Ch = ts_onehot_channels(dims)
  *    reward     int32  [N]
  *    valid      uint8  [N]              bit d set <=> move d changes the board
+ *    valid4     uint8  [N][4]           byte d = 1 <=> move d changes the board (the reference's list, as a 0 / 1 row)
  *
  * Preconditions on the level arrays (the reference never checks them either; its factory
  * guarantees them, environment.py:221-226): every cell id < S*S; the tiles of a board pairwise
@@ -55,7 +56,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 4
+#define TS_ABI_VERSION 5
 #define TS_MAX_SIZE 32   /* cell ids: uint8 up to 16x16, uint16 up to 32x32 (ts_cell_bytes) */
 #define TS_MAX_TILES 255 /* observation stores tile index + 1 in one byte */
 
@@ -133,6 +134,8 @@ typedef struct ts_step_out {
   uint8_t *valid;  /* [N]           optional, legality mask of the post-move board */
   uint8_t *obs_u8; /* [N][S][S][3]  optional, the observation as bytes (build-defined compact form:
                       every value of the reference observation is an integer 0..255) */
+  uint8_t *valid4; /* [N][4]        optional (ABI v5), the legality mask of the post-move board in the shape of the
+                      reference's get_valid_moves(): byte d = 1 iff Move d changes the board, else 0; 4-B aligned */
 } ts_step_out;
 
 /* --- introspection ------------------------------------------------------- */
@@ -172,6 +175,10 @@ int32_t ts_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions,
 /* get_valid_moves(): bit d of mask[n] set <=> Move d changes board n.  Ignores `done`.
  * ref: explainrl/environment/environment.py:149-171. */
 int32_t ts_valid_moves(const ts_dims *dims, const ts_state *st, uint8_t *mask, void *stream);
+/* The same as uint8 [N][4] (ABI v5): mask4[n][d] = 1 iff Move d changes board n, else 0 - column order = enum order, so
+ * the buffer IS the batched form of the reference's list (a bool [N, 4] view costs nothing).  mask4 4-B aligned.
+ * ref: explainrl/environment/environment.py:149-171. */
+int32_t ts_valid_moves4(const ts_dims *dims, const ts_state *st, uint8_t *mask4, void *stream);
 
 /* is_won(): won[n] = 1 if board n is solved as it stands, else 0.  multi_color: tile i on
  * target i for every i (and T == Tt); otherwise the set of tile cells equals the set of
@@ -257,6 +264,11 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
 #define TS_TUNE_LINES_BPW 3
 #define TS_TUNE_EMIT_EDGES 4
 #define TS_TUNE_XCD_PIECE 5
+#define TS_TUNE_XCD_SKEW 6  /* experiment (round 4): XCD x starts x * value blocks into its range / piece; default 0 */
+#define TS_TUNE_XCD_ORDER 7 /* experiment (round 4): order of the blocks inside a piece: 0 ascending, 1 bit-reversed, 2 descending */
+#define TS_TUNE_DEAL 8      /* 1 (default): boards up to 8x8 with 9 .. 64 tiles run with a board's tiles dealt over 4 or 8 lanes
+                             * (k_deal; TS_TUNE_LINES_LANES / ts_dims.lines_lanes = 4 or 8 choose for 9 .. 16 tiles); 0: one lane
+                             * per board as for any other tile count (k_small), kept for A/B and as the parity cross-check */
 int64_t ts_tuning(int32_t key, int64_t value);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */

@@ -19,7 +19,8 @@ MODE_STRICT, MODE_AUTORESET = 0, 1
 
 class Dims(C.Structure):
     _fields_ = [("n_boards", C.c_int64), ("size", C.c_int32), ("n_tiles", C.c_int32), ("n_targets", C.c_int32),
-                ("multi_color", C.c_int32), ("max_steps", C.c_int32), ("launch_hint", C.c_int32)]
+                ("multi_color", C.c_int32), ("max_steps", C.c_int32), ("launch_hint", C.c_int32), ("emit_edges", C.c_int32),
+                ("lines_lanes", C.c_int32), ("xcd_piece", C.c_int32)]  # the whole ts_dims of include/tiler_slider.h
 
 
 class State(C.Structure):
@@ -29,7 +30,7 @@ class State(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [("flags", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("onehot", C.c_void_p),
-                ("valid", C.c_void_p), ("obs_u8", C.c_void_p)]
+                ("valid", C.c_void_p), ("obs_u8", C.c_void_p), ("valid4", C.c_void_p)]
 
 
 def build(force=False):
@@ -188,7 +189,7 @@ class OracleBatch:
         self._check(lib().tso_reset(C.byref(self.dims), C.byref(self._state()), _p(obs)))
         return obs
 
-    def step(self, actions, mode=MODE_STRICT, obs=True, reward=False, onehot=False, valid=False, obs_u8=False):
+    def step(self, actions, mode=MODE_STRICT, obs=True, reward=False, onehot=False, valid=False, obs_u8=False, valid4=False):
         actions = np.ascontiguousarray(actions, np.uint8)
         assert actions.shape == (self.n,)
         out = {"flags": np.empty(self.n, np.uint8)}
@@ -202,8 +203,10 @@ class OracleBatch:
             out["valid"] = np.empty(self.n, np.uint8)
         if obs_u8:
             out["obs_u8"] = np.empty((self.n, self.size, self.size, 3), np.uint8)
+        if valid4:
+            out["valid4"] = np.empty((self.n, 4), np.uint8)
         so = StepOut(_p(out["flags"]), _p(out.get("obs")), _p(out.get("reward")), _p(out.get("onehot")),
-                     _p(out.get("valid")), _p(out.get("obs_u8")))
+                     _p(out.get("valid")), _p(out.get("obs_u8")), _p(out.get("valid4")))
         self._check(lib().tso_step(C.byref(self.dims), C.byref(self._state()), _p(actions), mode, C.byref(so)))
         return out
 

@@ -186,7 +186,9 @@ void tso_state_array(int32_t S, const uint8_t *blocked, int32_t T, const int32_t
  * ---------------------------------------------------------------------------------- */
 static int check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
-  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -3 || d->launch_hint > 3 ||
+  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 ||
+      d->emit_edges < 0 || d->emit_edges > 4 || d->xcd_piece < 0 || d->xcd_piece > (1 << 20) ||
+      (d->lines_lanes != 0 && d->lines_lanes != 4 && d->lines_lanes != 8 && d->lines_lanes != 16) || /* the launch-policy fields are ignored here, but the same ranges are refused (include/tiler_slider.h) */
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;
   if (d->size > TS_MAX_SIZE || d->n_tiles > TS_MAX_TILES || d->n_targets > TS_MAX_TILES) return TS_ERR_LIMIT;
@@ -288,12 +290,16 @@ static uint8_t valid_board(const ts_dims *d, const board *b) {
 }
 
 static void emit_extras(const ts_dims *d, const board *b, int64_t n, float *obs, int32_t *reward, float *onehot,
-                        uint8_t *valid) {
+                        uint8_t *valid, uint8_t *valid4) {
   const int C = d->size * d->size;
   if (obs) encode_board(d, b, obs + n * C * 3);
   if (reward) reward[n] = reward_board(d, b);
   if (onehot) onehot_board(d, b, onehot + n * (int64_t)onehot_channels(d) * C);
   if (valid) valid[n] = valid_board(d, b);
+  if (valid4) { /* the reference's list of valid moves as a 0 / 1 row in enum order (environment.py:159-169) */
+    const uint8_t m = valid_board(d, b);
+    for (int k = 0; k < 4; ++k) valid4[4 * n + k] = (uint8_t)((m >> k) & 1u);
+  }
 }
 
 /* build-defined compact observation: the float32 observation's values as bytes */
@@ -319,7 +325,7 @@ int32_t tso_reset(const ts_dims *d, const ts_state *st, float *obs) {
     store_tiles(d, st->pos, n, &b);
     st->step_count[n] = 0;
     st->done[n] = 0;
-    emit_extras(d, &b, n, obs, NULL, NULL, NULL);
+    emit_extras(d, &b, n, obs, NULL, NULL, NULL, NULL);
   }
   return TS_OK;
 }
@@ -373,7 +379,7 @@ int32_t tso_step(const ts_dims *d, const ts_state *st, const uint8_t *actions, u
       store_tiles(d, st->pos, n, &b);
     }
     out->flags[n] = flags;
-    emit_extras(d, &b, n, out->obs, out->reward, out->onehot, out->valid);
+    emit_extras(d, &b, n, out->obs, out->reward, out->onehot, out->valid, out->valid4);
     if (out->obs_u8) emit_obs_u8(d, &b, n, out->obs_u8);
   }
   return TS_OK;
@@ -416,7 +422,7 @@ int32_t tso_encode(const ts_dims *d, const ts_state *st, float *obs) {
     board b;
     load_level(d, st, n, &b);
     load_tiles(d, st->pos, n, &b);
-    emit_extras(d, &b, n, obs, NULL, NULL, NULL);
+    emit_extras(d, &b, n, obs, NULL, NULL, NULL, NULL);
   }
   return TS_OK;
 }
@@ -444,7 +450,7 @@ int32_t tso_encode_onehot(const ts_dims *d, const ts_state *st, float *onehot) {
     board b;
     load_level(d, st, n, &b);
     load_tiles(d, st->pos, n, &b);
-    emit_extras(d, &b, n, NULL, NULL, onehot, NULL);
+    emit_extras(d, &b, n, NULL, NULL, onehot, NULL, NULL);
   }
   return TS_OK;
 }
@@ -458,7 +464,7 @@ int32_t tso_reward(const ts_dims *d, const ts_state *st, int32_t *reward) {
     board b;
     load_level(d, st, n, &b);
     load_tiles(d, st->pos, n, &b);
-    emit_extras(d, &b, n, NULL, reward, NULL, NULL);
+    emit_extras(d, &b, n, NULL, reward, NULL, NULL, NULL);
   }
   return TS_OK;
 }

@@ -54,15 +54,22 @@ static long check_bitboard(int boards) {
     for (int p = 0; p < S * S; ++p)
       if (L.blocked[p]) blk |= M(1) << p;
     for (int i = 0; i < L.T; ++i) occ |= M(1) << (L.rows[i] * S + L.cols[i]);
+    const uint32_t vm = ts::valid_mask<S>(occ, blk);  // legality mask by free-neighbour tests
     for (int d = 0; d < 4; ++d) {
       std::vector<int32_t> r = L.rows, c = L.cols;
       tso_move(S, L.blocked.data(), L.T, r.data(), c.data(), 0, nullptr, nullptr, 0, d);
+      bool changed = false;  // environment.py:162-167: the move is valid iff the trial slide changed some tile
       for (int i = 0; i < L.T; ++i) {
         int np = ts::slide_cell<S>(L.rows[i] * S + L.cols[i], occ, blk, d);
+        changed |= r[i] != L.rows[i] || c[i] != L.cols[i];
         if (np != r[i] * S + c[i]) {
           if (bad < 5) std::fprintf(stderr, "bitboard S=%d dir=%d tile=%d got %d want %d\n", S, d, i, np, r[i] * S + c[i]);
           ++bad;
         }
+      }
+      if ((((vm >> d) & 1u) != 0) != changed) {
+        if (bad < 5) std::fprintf(stderr, "valid_mask S=%d dir=%d got %u want %d\n", S, d, (vm >> d) & 1u, (int)changed);
+        ++bad;
       }
     }
   }

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(L, sym), f"{sym} declared in include/tiler_slider.h but not exported"
     assert set(declared) == set(_cabi.EXPORTS)
-    assert L.ts_abi_version() == _cabi.ABI_VERSION == 4
+    assert L.ts_abi_version() == _cabi.ABI_VERSION == 5
     assert [L.ts_lines_words(s) for s in (0, 8, 9, 16, 17, 32, 33)] == [0, 0, 32, 32, 128, 128, 0]
     assert _cabi.limits() == (32, 255)
     assert [L.ts_blk_words(s) for s in (1, 4, 5, 6, 8, 15, 16, 20, 32)] == [1, 1, 1, 2, 2, 8, 8, 13, 32]
@@ -248,7 +248,7 @@ def test_bench_gpus_n_without_launcher_fails_cleanly_without_gpus(capsys):
 
 def test_level_records_keep_the_reference_names():
     """The level record under the reference's name (tests/test_user_scenarios.py:22-31 builds levels as
-    ImageLoader.ImageProcessed); the image parser and its constants are out of scope."""
+    ImageLoader.ImageProcessed); the parser itself: tests/test_levels_from_screenshots.py."""
     from tiler_slider_amd import ImageLoader, Level, TilerSliderEnv
     lvl = ImageLoader.ImageProcessed(size=5, blocked_locations=[(1, 1), (2, 2)], initial_locations=[(0, 0)],
                                      target_locations=[(4, 4)])
@@ -257,14 +257,20 @@ def test_level_records_keep_the_reference_names():
                                                                initial_locations=[(0, 3), (3, 2)],
                                                                target_locations=[(0, 0), (3, 0)], multiple_colors=True))
     assert env.multi_color is True and env.size == 4
-    with pytest.raises(NotImplementedError):
-        ImageLoader.parse_puzzle_image(np.zeros((10, 10, 3)), False)
+    # the reference's class constants (tests/test_dataloader.py:64-95)
+    for name, want in (("BACKGROUND_COLOR", [0, 172, 194]), ("EMPTY_TILE_COLOR", [223, 247, 249]), ("COLOR_TOLERANCE", [10, 10, 10])):
+        c = getattr(ImageLoader, name)
+        assert isinstance(c, np.ndarray) and c.shape == (3,) and c.tolist() == want
+    raw = ImageLoader.ImageRawData(name="test.jpg", puzzle_image=np.zeros((100, 100, 3)), level_label=np.zeros((50, 50, 3)),
+                                   target_moves=np.zeros((50, 50, 3)))
+    assert raw.name == "test.jpg" and raw.puzzle_image.shape == (100, 100, 3)
 
 
 def test_no_64bit_read_of_the_last_allocated_vgpr():
     """gfx950: a 64-bit shift whose shift amount sits in the LAST register of the wave's VGPR allocation occasionally
-    reads v0 instead (profiles/r03_wrong_slide_isa.md).  The build pads such allocations; the scanner checks the
-    shipped code object instruction by instruction."""
+    reads v0 instead (profiles/r03_wrong_slide_isa.md).  The build scans the unpadded object, pads allocations (always
+    below 64 registers, from 64 on only on a scanner hit), scans again and fails on a hit; this re-checks the shipped
+    code object instruction by instruction."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import scan_last_vgpr
@@ -275,13 +281,25 @@ def test_no_64bit_read_of_the_last_allocated_vgpr():
 
 
 def test_vgpr_allocation_padding_rule():
+    """Descriptor AND metadata are edited; 48 (fills its allocation, below 64) is padded, 49 / 33 are not; from 64 on a
+    kernel is padded only when the scanner named it (a granule more costs a wave per SIMD there)."""
     asm = "\n".join([
         "\t.amdhsa_kernel k_full", "\t\t.amdhsa_next_free_vgpr 48", "\t\t.amdhsa_accum_offset 48", "\t.end_amdhsa_kernel",
-        "\t.amdhsa_kernel k_slack", "\t\t.amdhsa_next_free_vgpr 33", "\t.end_amdhsa_kernel",
+        "\t.amdhsa_kernel k_slack", "\t\t.amdhsa_next_free_vgpr 49", "\t.end_amdhsa_kernel",
+        "\t.amdhsa_kernel k_big_clean", "\t\t.amdhsa_next_free_vgpr 64", "\t.end_amdhsa_kernel",
+        "\t.amdhsa_kernel k_big_hit", "\t\t.amdhsa_next_free_vgpr 96", "\t.end_amdhsa_kernel",
         "amdhsa.kernels:", "  - .agpr_count:     0", "    .name:           k_full", "    .vgpr_count:     48",
-        "  - .agpr_count:     0", "    .name:           k_slack", "    .vgpr_count:     33"])
-    from tiler_slider_amd import _cabi
+        "  - .agpr_count:     0", "    .name:           k_slack", "    .vgpr_count:     49",
+        "  - .agpr_count:     0", "    .name:           k_big_clean", "    .vgpr_count:     64",
+        "  - .agpr_count:     0", "    .name:           k_big_hit", "    .vgpr_count:     96"])
+    from tiler_slider_amd import _cabi, _vgpr_guard
+    out, padded = _vgpr_guard.pad_vgpr_allocations(asm, hits={"k_big_hit"})
+    assert padded == {"k_full": (48, "free"), "k_big_hit": (96, "hit")}
+    for name, n in (("k_full", 49), ("k_slack", 49), ("k_big_clean", 64), ("k_big_hit", 97)):
+        assert re.search(rf"\.amdhsa_kernel {name}\n\s+\.amdhsa_next_free_vgpr {n}\b", out), name
+        assert re.search(rf"\.name:\s+{name}\n\s+\.vgpr_count:\s+{n}\b", out), name
+    assert ".amdhsa_accum_offset 48" in out
+    # blanket rule (round 3) through the _cabi wrapper: every full allocation
     out, n = _cabi.pad_vgpr_allocations(asm)
-    assert n == 1
-    assert ".amdhsa_next_free_vgpr 49" in out and ".amdhsa_next_free_vgpr 33" in out and ".amdhsa_accum_offset 48" in out
-    assert re.search(r"\.name:\s+k_full\n\s+\.vgpr_count:\s+49", out) and re.search(r"\.name:\s+k_slack\n\s+\.vgpr_count:\s+33", out)
+    assert n == 3 and ".amdhsa_next_free_vgpr 65" in out
+    assert [_vgpr_guard.waves_per_simd(v) for v in (32, 64, 65, 96, 97, 128, 129)] == [8, 8, 7, 5, 4, 4, 3]

@@ -155,7 +155,7 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
         if step == 5:
             act[::13] = 9  # invalid action bytes: flagged, board untouched
         obs, done, info = env.step(torch.from_numpy(act))
-        want = ref.step(act, mode=mode, reward=True, onehot=True, valid=True)
+        want = ref.step(act, mode=mode, reward=True, onehot=True, valid=True, valid4=True)
         ctx = f"S={S} T={T} step={step}"
         _assert_plain_step(plain, torch.from_numpy(act), ref, want, ctx)
         np.testing.assert_array_equal(env.positions.cpu().numpy(), ref.pos, err_msg=ctx)
@@ -166,6 +166,9 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
         np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
         np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
         np.testing.assert_array_equal(env._valid.cpu().numpy(), want["valid"], err_msg=ctx)
+        # the same mask in the reference's shape (ts_step_out.valid4): bool [N, 4] in enum order, against the oracle's own rows
+        assert info["valid_moves"].dtype == torch.bool and tuple(info["valid_moves"].shape) == (N, 4)
+        np.testing.assert_array_equal(info["valid_moves"].cpu().numpy(), want["valid4"] != 0, err_msg=ctx)
         if env8 is not None:
             obs8, _, info8 = env8.step(torch.from_numpy(act))
             np.testing.assert_array_equal(obs8.cpu().numpy(), want["obs"].astype(np.uint8), err_msg=ctx)
@@ -440,6 +443,9 @@ LARGE_BATCH_SHAPES = [
     # (profiles/r03_wrong_slide_isa.md); found by tools/scan_last_vgpr.py, not by a test: the shape was not covered at scale
     (8, 5, 10, True, 300_000), (8, 5, 10, False, 300_000), (7, 5, 8, True, 300_000), (6, 7, 4, True, 250_000), (8, 3, 10, True, 300_000),
     (8, 1, 10, False, 300_000), (8, 4, 6, True, 300_000), (8, 6, 6, False, 300_000), (8, 7, 6, True, 300_000), (7, 3, 5, False, 300_000),
+    # more than 8 tiles on boards up to 8x8: a board's tiles dealt over 4 / 8 lanes (k_deal, round 4), every (lanes, tiles per lane) form
+    (8, 20, 10, True, 300_000), (8, 12, 8, False, 300_000), (6, 12, 4, True, 250_000), (8, 40, 5, False, 200_000), (5, 12, 3, True, 300_000),
+    (4, 10, 2, False, 300_000), (7, 17, 6, True, 250_000), (8, 64, 0, True, 100_000),
 ]
 
 
@@ -513,6 +519,72 @@ def test_lines_kernel_lanes_per_board_forced(torch_cuda, oracle, lanes, S, T, Tt
             np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
     finally:
         L.ts_tuning(_cabi.TUNE_LINES_LANES, before)
+        L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, nt_before)
+
+
+@pytest.mark.parametrize("form", ["policy", "lanes8", "one_lane"])
+@pytest.mark.parametrize("S,T,Tt,K,mc,N", [(4, 10, 10, 2, True, 1031), (4, 16, 16, 0, False, 130), (5, 12, 12, 4, False, 517), (5, 20, 20, 3, True, 777),
+                                           (5, 25, 25, 0, True, 67), (6, 9, 9, 6, True, 640), (6, 17, 17, 5, False, 333), (6, 33, 33, 1, True, 200),
+                                           (7, 12, 12, 9, True, 321), (7, 40, 40, 3, False, 259), (8, 9, 9, 8, False, 1500), (8, 16, 16, 10, True, 900),
+                                           (8, 17, 17, 10, True, 513), (8, 20, 20, 10, True, 4099), (8, 32, 32, 10, False, 258), (8, 33, 33, 5, True, 131),
+                                           (8, 64, 64, 0, False, 66), (6, 10, 12, 4, True, 300), (8, 12, 9, 8, False, 301), (8, 3, 20, 9, True, 302),
+                                           (7, 20, 2, 6, False, 303), (5, 0, 12, 3, False, 65), (8, 30, 64, 4, True, 129)])
+def test_dealt_tiles_kernel_forms(torch_cuda, oracle, form, S, T, Tt, K, mc, N):
+    """Boards up to 8x8 with 9 .. 64 tiles / targets: k_deal deals a board's tiles over 4 or 8 lanes (round 4).  Every form
+    (the policy's; 8 lanes forced for 9 .. 16 tiles; the old one-lane-per-board path, TS_TUNE_DEAL = 0) must give the oracle's
+    outputs - optional outputs, uint8 observation, duplicate targets, unequal counts, cache-resident and out-of-cache kernels."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    L = _cabi.lib()
+    blk, init, _ = oracle.generate(S, T, 0, K, N, seed=900 + S + T)
+    _, _, tgt = oracle.generate(S, 0, min(Tt, S * S), 0, N, seed=950 + S + Tt)
+    if Tt > S * S:  # more targets than cells: repeat them
+        tgt = np.concatenate([tgt, tgt[: Tt - S * S]])
+    if Tt >= 2:
+        tgt[1, 3::11] = tgt[0, 3::11]  # duplicate targets: the "highest index wins" fix-up
+    if T == Tt and T:
+        tgt[:, ::7] = init[:, ::7]      # some boards solved at the start
+    lanes_before = L.ts_tuning(_cabi.TUNE_LINES_LANES, 8 if form == "lanes8" else 0)
+    deal_before = L.ts_tuning(_cabi.TUNE_DEAL, 0 if form == "one_lane" else 1)
+    nt_before = L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, -1)
+    try:
+        for nt in (nt_before, 0):
+            L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, nt)
+            ref = oracle.OracleBatch(S, mc, 7, blk, init, tgt)
+            env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True, with_reward=True,
+                                                with_onehot=True, with_valid_moves=True)
+            plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True)
+            env8 = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True, obs_dtype="uint8")
+            want0 = ref.reset()
+            np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
+            np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
+            np.testing.assert_array_equal(env8.reset().cpu().numpy(), want0.astype(np.uint8))
+            for step in range(10):
+                act = oracle.fill_actions(N, seed=41 + S, step_index=step)
+                if step == 4:
+                    act[::13] = 9  # invalid action bytes: flagged, board untouched
+                obs, done, info = env.step(torch.from_numpy(act))
+                want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True, onehot=True, valid=True, valid4=True)
+                ctx = f"form={form} nt={nt} S={S} T={T} Tt={Tt} step={step}"
+                _assert_plain_step(plain, torch.from_numpy(act), ref, want, ctx)
+                np.testing.assert_array_equal(env.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64), err_msg=ctx)
+                np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+                np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"], err_msg=ctx)
+                np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
+                np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
+                np.testing.assert_array_equal(env._valid.cpu().numpy(), want["valid"], err_msg=ctx)
+                np.testing.assert_array_equal(info["valid_moves"].cpu().numpy(), want["valid4"] != 0, err_msg=ctx)
+                obs8, _, info8 = env8.step(torch.from_numpy(act))
+                np.testing.assert_array_equal(obs8.cpu().numpy(), want["obs"].astype(np.uint8), err_msg=ctx)
+                np.testing.assert_array_equal(info8["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+            np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
+            np.testing.assert_array_equal(env.get_valid_moves().cpu().numpy(), (ref.valid_moves()[:, None] >> np.arange(4)) & 1 != 0)
+            np.testing.assert_array_equal(env.encode().cpu().numpy(), ref.encode())
+            np.testing.assert_array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
+            np.testing.assert_array_equal(env.reward().cpu().numpy(), ref.reward())
+    finally:
+        L.ts_tuning(_cabi.TUNE_LINES_LANES, lanes_before)
+        L.ts_tuning(_cabi.TUNE_DEAL, deal_before)
         L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, nt_before)
 
 

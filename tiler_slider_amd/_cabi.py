@@ -15,17 +15,18 @@ SRC = os.path.join(_PKG, "csrc", "ts_kernels.hip")
 HEADERS = [os.path.join(_PKG, "csrc", "ts_core.h"), os.path.join(ROOT, "include", "tiler_slider.h")]
 LIB_PATH = os.path.join(_PKG, "lib", "libtiler_slider_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 OK, ERR_NULL, ERR_DIMS, ERR_LIMIT, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0x08
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
 MODE_STRICT, MODE_AUTORESET = 0, 1
 TUNE_MULTI_MIN_BOARDS, TUNE_NT_THRESHOLD_BYTES, TUNE_LINES_LANES, TUNE_LINES_BPW, TUNE_EMIT_EDGES, TUNE_XCD_PIECE = 0, 1, 2, 3, 4, 5
+TUNE_XCD_SKEW, TUNE_XCD_ORDER, TUNE_DEAL = 6, 7, 8
 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
            "ts_encode_u8", "ts_expand_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions",
-           "ts_lines_words", "ts_prepare", "ts_generate_mt19937", "ts_tuning")
+           "ts_lines_words", "ts_prepare", "ts_generate_mt19937", "ts_tuning", "ts_valid_moves4")
 
 
 class Dims(C.Structure):
@@ -41,7 +42,7 @@ class State(C.Structure):
 
 class StepOut(C.Structure):
     _fields_ = [("flags", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("onehot", C.c_void_p),
-                ("valid", C.c_void_p), ("obs_u8", C.c_void_p)]
+                ("valid", C.c_void_p), ("obs_u8", C.c_void_p), ("valid4", C.c_void_p)]
 
 
 class TilerSliderLibraryError(RuntimeError):
@@ -56,39 +57,16 @@ def _stale():
 
 
 _LLVM_BIN = "/opt/rocm/lib/llvm/bin"
-_VGPR_GRANULE = 8  # gfx90a+ allocate VGPRs in blocks of 8
 
 
-def pad_vgpr_allocations(asm):
-    """gfx950 hazard workaround on the device assembly (profiles/r03_wrong_slide_isa.md): a 64-bit shift whose shift
-    amount lives in the LAST register of the wave's VGPR allocation (v31 of 32, v47 of 48 ...) occasionally reads the
-    wave's v0 instead when a second wave shares the SIMD - tiles slid past their row in 2-7 % of 8x8 boards.  The
-    compiler knows no such hazard, so every kernel whose VGPR count fills its allocation exactly gets one register more
-    in its descriptor (allocation + 8): the last allocated register is then never one the code touches.  Costs nothing
-    below 64 registers (8 waves per SIMD either way).  Returns (patched assembly, number of kernels padded)."""
-    import re
-    padded, out, in_meta, name = set(), [], False, None
-    kernel = None
-    for line in asm.split("\n"):
-        t = line.strip()
-        if t.startswith(".amdhsa_kernel "):
-            kernel = t.split()[1]
-        elif t.startswith(".amdhsa_next_free_vgpr ") and kernel:
-            n = int(t.split()[1])
-            if n > 0 and n % _VGPR_GRANULE == 0:
-                if n + 1 > 512:
-                    raise TilerSliderLibraryError(f"{kernel}: cannot pad {n} VGPRs")
-                line = line.replace(str(n), str(n + 1))
-                padded.add(kernel)
-        elif t == "amdhsa.kernels:":
-            in_meta = True
-        elif in_meta and t.startswith(".name:"):
-            name = t.split(":", 1)[1].strip()
-        elif in_meta and t.startswith(".vgpr_count:") and name in padded:
-            n = int(t.split(":")[1])
-            line = re.sub(r"\d+\s*$", str(n + 1), line)
-        out.append(line)
-    return "\n".join(out), len(padded)
+def pad_vgpr_allocations(asm, hits=None):
+    """(patched assembly, number of kernels padded): see _vgpr_guard.pad_vgpr_allocations."""
+    from . import _vgpr_guard
+    try:
+        out, padded = _vgpr_guard.pad_vgpr_allocations(asm, hits)
+    except ValueError as e:
+        raise TilerSliderLibraryError(str(e)) from e
+    return out, len(padded)
 
 
 def _run(cmd, verbose):
@@ -99,36 +77,80 @@ def _run(cmd, verbose):
         raise TilerSliderLibraryError(f"build step failed ({res.returncode}): {' '.join(cmd)}")
 
 
-def build_library(force=False, verbose=False):
-    """Compile the HIP kernels for gfx950 in-tree (hipcc cross-compiles without a GPU).  The steps are hipcc's own
-    (`hipcc -###`), taken apart so that the device assembly can be post-processed between compiler and assembler
-    (pad_vgpr_allocations):  device code -> assembly -> [pad] -> object -> code object -> fat binary -> host compile."""
-    if not force and not _stale():
-        return LIB_PATH
+def compile_guarded(src, out_lib, defines=(), work=None, verbose=False, keep_asm=False):
+    """hipcc's own steps (`hipcc -###`) taken apart so that the device assembly can be post-processed between compiler
+    and assembler:  device code -> assembly -> [scan the unpadded object, pad VGPR allocations] -> object -> code object
+    -> [scan again: any finding fails the build] -> fat binary -> host compile.  The gfx950 hazard and the padding policy
+    are described in _vgpr_guard.py.  `defines`: extra -D flags (tools/variant_bench.py builds its A/B variants through
+    this function, so that no variant runs without the guard).  Returns the guard's report (also written next to the
+    intermediate files as vgpr_guard.json)."""
+    import json
+    from . import _vgpr_guard as guard
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise TilerSliderLibraryError("hipcc not found: cannot build libtiler_slider_hip.so")
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
-    work = os.path.join(ROOT, "build", "lib")
+    work = work or os.path.join(ROOT, "build", "lib")
     os.makedirs(work, exist_ok=True)
-    base = os.path.join(work, "ts_kernels.gfx950")
-    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall"]
-    _run([hipcc, *common, "-S", "--cuda-device-only", "-o", base + ".raw.s", SRC], verbose)
-    asm, n_padded = pad_vgpr_allocations(open(base + ".raw.s").read())
+    os.makedirs(os.path.dirname(out_lib), exist_ok=True)
+    base = os.path.join(work, os.path.splitext(os.path.basename(out_lib))[0] + ".gfx950")
+    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wall", *defines]
+
+    def assemble(asm_path, tag):
+        _run([f"{_LLVM_BIN}/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm_path, "-o", base + tag + ".o"], verbose)
+        _run([f"{_LLVM_BIN}/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", base + tag + ".hsaco", base + tag + ".o"], verbose)
+        return base + tag + ".hsaco"
+
+    _run([hipcc, *common, "-S", "--cuda-device-only", "-o", base + ".raw.s", src], verbose)
+    raw = open(base + ".raw.s").read()
+    a0, b0, counts0 = guard.scan_code_object(assemble(base + ".raw.s", ".raw"))
+    hits = {k for k, _ in a0} | {k for k, _ in b0}
+    try:
+        asm, padded = guard.pad_vgpr_allocations(raw, hits)
+    except ValueError as e:
+        raise TilerSliderLibraryError(str(e)) from e
     open(base + ".s", "w").write(asm)
-    _run([f"{_LLVM_BIN}/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", base + ".s", "-o", base + ".o"], verbose)
-    _run([f"{_LLVM_BIN}/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", base + ".hsaco", base + ".o"], verbose)
+    hsaco = assemble(base + ".s", "")
+    a1, b1, counts1 = guard.scan_code_object(hsaco)
+    full = sorted(k for k, (n, ag) in counts0.items() if n and (n + ag) % guard.GRANULE == 0 and ag == 0)
+    report = {
+        "kernels": len(counts0), "allocation_full": len(full), "padded": len(padded),
+        "padded_free_below_64": sum(1 for n, r in padded.values() if r == "free"),
+        "hits_in_unpadded_object": {"class_a": len(a0), "class_b": len(b0), "kernels": sorted(hits)},
+        # kernels at or above 64 registers whose count fills the allocation: a granule more costs a wave per SIMD there
+        "at_or_above_64": [{"kernel": k, "vgprs": counts0[k][0], "padded": k in padded,
+                            "waves_per_simd": guard.waves_per_simd(counts0[k][0]),
+                            "waves_per_simd_if_padded": guard.waves_per_simd(counts0[k][0] + 1)}
+                           for k in full if counts0[k][0] >= guard.FREE_BELOW],
+        "hits_in_final_object": {"class_a": len(a1), "class_b": len(b1)},
+    }
+    json.dump(report, open(os.path.join(work, "vgpr_guard.json"), "w"), indent=1)
+    if a1 or b1:
+        raise TilerSliderLibraryError(f"VGPR hazard guard: the padded code object still has {len(a1)} class A / {len(b1)} class B "
+                                      f"reads of a last allocated VGPR: {(a1 + b1)[:3]}")
+    if not full:
+        raise TilerSliderLibraryError("VGPR hazard guard: no kernel metadata was parsed from the device assembly")
     _run([f"{_LLVM_BIN}/clang-offload-bundler", "-type=o", "-bundle-align=4096",
-          "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={base}.hsaco",
+          "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", f"-input={hsaco}",
           f"-output={base}.hipfb"], verbose)
-    tmp = LIB_PATH + ".tmp"
+    tmp = out_lib + ".tmp"
     _run([hipcc, *common, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", base + ".hipfb", "-shared", "-fPIC",
-          "-o", tmp, SRC], verbose)
-    os.replace(tmp, LIB_PATH)
-    for ext in (".raw.s", ".o", ".hsaco", ".hipfb") + (() if os.environ.get("TS_KEEP_ASM") == "1" else (".s",)):
-        os.remove(base + ext)
+          "-o", tmp, src], verbose)
+    os.replace(tmp, out_lib)
+    for ext in (".raw.s", ".raw.o", ".raw.hsaco", ".o", ".hsaco", ".hipfb") + (() if keep_asm else (".s",)):
+        if os.path.exists(base + ext):
+            os.remove(base + ext)
     if verbose:
-        print(f"padded the VGPR allocation of {n_padded} kernels")
+        print(f"VGPR guard: {report['padded']} of {report['allocation_full']} full allocations padded "
+              f"({report['padded_free_below_64']} below 64 registers, {len(hits)} on a scanner hit); "
+              f"{sum(1 for e in report['at_or_above_64'] if not e['padded'])} at or above 64 left alone (no 64-bit read of the last register)")
+    return report
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP kernels for gfx950 in-tree (hipcc cross-compiles without a GPU), through compile_guarded."""
+    if not force and not _stale():
+        return LIB_PATH
+    compile_guarded(SRC, LIB_PATH, verbose=verbose, keep_asm=os.environ.get("TS_KEEP_ASM") == "1")
     return LIB_PATH
 
 
@@ -172,7 +194,7 @@ def lib():
     L.ts_check_dims.restype = C.c_int32
     for name, args in (("ts_reset", [DP, SP, P, P]),
                        ("ts_step", [DP, SP, P, C.c_uint32, C.POINTER(StepOut), P]),
-                       ("ts_valid_moves", [DP, SP, P, P]), ("ts_is_won", [DP, SP, P, P]), ("ts_prepare", [DP, SP, P, P]),
+                       ("ts_valid_moves", [DP, SP, P, P]), ("ts_valid_moves4", [DP, SP, P, P]), ("ts_is_won", [DP, SP, P, P]), ("ts_prepare", [DP, SP, P, P]),
                        ("ts_encode", [DP, SP, P, P]), ("ts_encode_u8", [DP, SP, P, P]),
                        ("ts_encode_onehot", [DP, SP, P, P]), ("ts_reward", [DP, SP, P, P]),
                        ("ts_generate", [DP, SP, C.c_uint64, C.c_int64, C.c_int32, P]),

@@ -77,7 +77,29 @@ TS_HD int slide_cell(int p, M occ, M blk, int dir) {
   return neg ? dest + st * ahead : dest - st * ahead;
 }
 
-// The same on one lane of a large board: x = index of the tile along the lane (0..S-1),
+// Legality mask of a board (ref: explainrl/environment/environment.py:149-171: the moves whose trial slide changes some
+// tile): bit d set <=> move d changes the board.  A slide in direction d changes the board iff some tile has a FREE
+// neighbour cell (in-bounds, no obstacle, no tile) in that direction: inside a packed run - the fixed point of the slide -
+// every tile touches the wall, an obstacle or the next tile; and a tile with a free cell in front of it moves, or a tile
+// further along its run does.  Four shifts of the bitboard instead of four trial slides per tile; checked against the
+// oracle's four trial moves on every test shape, and on the host in tests/native/core_check.cpp.
+template <int S, typename M = typename Bitboard<S>::mask_t>
+TS_HD uint32_t valid_mask(M occ, M blk) {
+  using BB = Bitboard<S>;
+  constexpr M full = BB::C == 64 ? ~M(0) : (M(1) << (BB::C & 63)) - 1;
+  constexpr M first_col = BB::col0(), last_col = M(BB::col0() << (S - 1));
+  const M free_cells = M(~(occ | blk)) & full;
+  uint32_t vm = 0;
+  if constexpr (S > 1) {
+    vm |= (M(occ >> S) & free_cells) ? 1u : 0u;                       // UP: the cell one row above
+    vm |= (M(occ << S) & free_cells) ? 2u : 0u;                       // DOWN
+    vm |= (M(M(occ & ~first_col) >> 1) & free_cells) ? 4u : 0u;       // LEFT
+    vm |= (M(M(occ & ~last_col) << 1) & free_cells) ? 8u : 0u;        // RIGHT
+  }
+  return vm;
+}
+
+// slide_cell on one lane of a large board: x = index of the tile along the lane (0..S-1),
 // B / O = obstacle / tile bits of that lane (bit i = i-th cell along the lane), neg = the
 // move goes towards index 0.  Returns the new index.
 TS_HD int slide_line(int x, uint32_t B, uint32_t O, int S, bool neg) {

@@ -98,6 +98,9 @@
 #ifndef TS_WAVES_PER_BLOCK
 #define TS_WAVES_PER_BLOCK 4
 #endif
+#ifndef TS_DEAL_LANES_SMALL  // lanes per board of k_deal for 9 .. 16 tiles (4 or 8)
+#define TS_DEAL_LANES_SMALL 4
+#endif
 #ifndef TS_LINES_LDS_PAD  // diagnostic: extra dynamic LDS per wave of k_lines (lowers the resident waves)
 #define TS_LINES_LDS_PAD 0
 #endif
@@ -165,6 +168,9 @@ struct KArgs {
   uint32_t bpw;         // boards per wave (k_small: 64, k_lines: 4; fewer beyond the Infinity Cache)
   uint32_t xcd_piece;   // block -> board-range mapping (xcd_contiguous_block): 0 = one contiguous eighth per XCD, P = pieces of P blocks
   uint32_t emit_edges;  // out-of-cache launches: bit 0 / 1 = first / last store instruction of a wave's chunk as write-back stores
+  uint32_t xcd_skew;    // experiment (ts_tuning): XCD x starts x * skew blocks into its range / piece (wrapping around)
+  uint32_t xcd_order;   // experiment (ts_tuning): order inside a piece: 0 ascending, 1 bit-reversed, 2 descending
+  uint8_t *valid4;      // legality mask as the reference's shape: uint8 [N][4], 0 / 1 per move
 };
 
 // Orders LDS traffic between the lanes of ONE wave.  The hardware executes a wave's DS
@@ -221,6 +227,9 @@ __device__ __forceinline__ void store16_policy(void *dst, f32x4 v) {
 __device__ __forceinline__ void store4_agent_scope(void *dst, uint32_t v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v));
 }
+
+// legality bits 0..3 -> four bytes 0 / 1 (one row of the reference-shaped uint8 [N][4] mask; little-endian: byte d = Move d)
+__device__ __forceinline__ uint32_t spread_valid(uint32_t vm) { return (vm & 1u) | ((vm & 2u) << 7) | ((vm & 4u) << 14) | ((vm & 8u) << 21); }
 
 template <bool NT>
 __device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
@@ -378,7 +387,7 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 //     non-coherent L2s.
 // `piece` (KArgs.xcd_piece, round 3): 0 = each XCD owns one contiguous eighth of the batch; P > 0 = pieces of P consecutive
 // blocks per XCD, dealt round-robin over the eight XCDs, so that the eight write fronts stay within 8 * P blocks of each other.
-__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks, uint32_t piece = 0) {
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks, uint32_t piece = 0, uint32_t skew = 0, uint32_t order = 0) {
 #if TS_XCD_REMAP
 #if TS_XCD_PIECE > 0
   piece = TS_XCD_PIECE;
@@ -387,9 +396,17 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
     const uint32_t full = nblocks / (8u * piece) * (8u * piece);
     if (bid >= full) return bid;
     const uint32_t xcd = bid & 7u, k = bid >> 3;
-    return ((k / piece) * 8u + xcd) * piece + (k % piece);
+    uint32_t i = k % piece;
+    if (skew) i = (i + xcd * skew) % piece;
+    if (order == 1 && (piece & (piece - 1)) == 0 && piece > 1) i = __brev(i) >> (__clz(piece) + 1);
+    if (order == 2) i = piece - 1 - i;
+    return ((k / piece) * 8u + xcd) * piece + i;
   }
   const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u;
+  if (skew) {
+    const uint32_t qx = xcd < r ? q + 1 : q;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((bid >> 3) + xcd * skew) % qx;
+  }
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 #else
   return bid;
@@ -425,7 +442,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   // a.bpw boards per wave: 64 (one per lane), or fewer for launches beyond the Infinity Cache (the
   // upper lanes idle; a wave's contiguous chunk of output shrinks accordingly)
   const int bpw = (int)a.bpw;
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece) * (blockDim.x >> 6) + wave) * bpw;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece, a.xcd_skew, a.xcd_order) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform; no block-level barrier exists in this kernel
   const int64_t N = a.N;
   const int64_t n = n0 + lane;
@@ -626,23 +643,12 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   if (live && a.flags && (TS_ABLATE != 3 || flags == 0xEE)) a.flags[n] = (uint8_t)flags;
 
   // ---- legality mask of the post-move board (environment.py:149-171) ----
-  if (EXTRAS && a.valid) {
-    uint32_t vm = 0;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      bool moved = false;
-      if constexpr (TFIX > 0) {
-#pragma unroll
-        for (int t = 0; t < TFIX; ++t) moved |= ts::slide_cell<S>(q[t], occ2, blk, d) != q[t];
-      } else {
-        for (int t = 0; t < T; ++t) {
-          const int qt = st_np[t * kWave + lane];
-          moved |= ts::slide_cell<S>(qt, occ2, blk, d) != qt;
-        }
-      }
-      vm |= (moved ? 1u : 0u) << d;
-    }
-    if (live) a.valid[n] = (uint8_t)vm;
+  if (EXTRAS && (a.valid || a.valid4)) {
+    // a move changes the board iff some tile has a free neighbour cell in its direction (ts::valid_mask): four shifts of
+    // the bitboard instead of four trial slides per tile (round 4)
+    const uint32_t vm = ts::valid_mask<S>(occ2, blk);
+    if (live && a.valid) a.valid[n] = (uint8_t)vm;
+    if (live && a.valid4) reinterpret_cast<uint32_t *>(a.valid4)[n] = spread_valid(vm);
   }
 
   // ---- build-defined Manhattan reward ----
@@ -874,6 +880,7 @@ __global__ __launch_bounds__(256) void k_multi(const KArgs a) {
   }
 
   P out_pos[TFIX], out_done = 0, out_flags = 0, out_valid = 0;
+  V out_valid4 = {};
 #pragma unroll
   for (int t = 0; t < TFIX; ++t) out_pos[t] = 0;
   V out_sc = {}, out_rw = {};
@@ -942,16 +949,10 @@ __global__ __launch_bounds__(256) void k_multi(const KArgs a) {
     out_done |= (P)((P)d << sh);
     out_flags |= (P)((P)flags << sh);
 
-    if (EXTRAS && a.valid) {  // legality mask of the post-move board (environment.py:149-171)
-      uint32_t vm = 0;
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) {
-        bool moved = false;
-#pragma unroll
-        for (int t = 0; t < TFIX; ++t) moved |= ts::slide_cell<S>(q[t], occ2, blk, dd) != q[t];
-        vm |= (moved ? 1u : 0u) << dd;
-      }
+    if (EXTRAS && (a.valid || a.valid4)) {  // legality mask of the post-move board (environment.py:149-171)
+      const uint32_t vm = ts::valid_mask<S>(occ2, blk);
       out_valid |= (P)((P)vm << sh);
+      set_word(out_valid4, g, spread_valid(vm));
     }
     if (EXTRAS && a.reward) {  // build-defined Manhattan reward
       int sum = 0;
@@ -993,12 +994,271 @@ __global__ __launch_bounds__(256) void k_multi(const KArgs a) {
     }
     if (a.flags) *reinterpret_cast<P *>(a.flags + n) = out_flags;
     if (EXTRAS && a.valid) *reinterpret_cast<P *>(a.valid + n) = out_valid;
+    if (EXTRAS && a.valid4) *reinterpret_cast<V *>(reinterpret_cast<uint32_t *>(a.valid4) + n) = out_valid4;
     if (EXTRAS && a.reward) *reinterpret_cast<V *>(a.reward + n) = out_rw;
   }
   if (a.obs || a.obs_u8) {
     wave_sync();
     if (a.obs) emit_bytes_as_f32<false>(img, a.obs + n0 * (3 * C), nb * 3 * C, lane);
     if (a.obs_u8) emit_bytes_raw<16, false>(img, a.obs_u8 + n0 * (3 * C), nb * 3 * C, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_deal<S, G, TPL, EXTRAS, NT>: S <= 8 with MORE THAN 8 TILES (round 4): a board's tiles dealt over G = 4 or 8 lanes.
+//
+// k_small keeps a board in ONE lane; beyond its register forms (n_tiles == n_targets <= 8) that lane walks all T tiles
+// through LDS-staged cells, serially, three times (occupancy, slide, image) - latency-bound: 8x8 with 20 tiles ran at 0.76
+// of the HBM roofline where 8x8 with 4 tiles runs at 0.89 (profiles/r03_shape_sweep.log).  Here, as in k_lines, tile t
+// lives in a register of lane t mod G of its board's group, a wave carries 64 / G boards, and the whole-board quantities
+// (pre- / post-move occupancy, target mask) are OR-reduced over the group with G - 1 ... log2 G shuffles.  The obstacle
+// bitboard, the action and the counters are loaded by all G lanes of a group from the same address (one request).
+//   * slide: ts::slide_cell on the group's occupancy bitboard - the arithmetic of k_small, TPL tiles per lane;
+//   * win / invalid-move: __ballot over the group;
+//   * legality mask: a move changes the board iff some tile has a FREE neighbour cell in that direction (k_lines'
+//     argument: in a packed run every tile touches a tile, an obstacle or the wall) - four shifts of the bitboard;
+//   * duplicate target cells ("highest index wins", state.py:209-211) show as popcount(target mask) != n_targets and
+//     are fixed up as in k_lines;
+//   * one-hot planes: the wave's boards as one stream cut into 8 KiB pieces, as in k_lines.
+// Host policy (launch()): 9 .. 16 tiles G = 4 / TPL = 4 (or G = 8 / TPL = 2), up to 32 G = 8 / TPL = 4, up to 64 G = 8 / TPL = 8;
+// anything else (n_targets > 64: repeated targets) stays with k_small's any-tile-count path.
+// ------------------------------------------------------------------------------------------
+template <int G, typename M>
+__device__ __forceinline__ M group_or(M v) {
+#pragma unroll
+  for (int o = G >> 1; o > 0; o >>= 1) v |= __shfl_xor(v, o, kWave);
+  return v;
+}
+
+template <int S, int G, int TPL, bool EXTRAS, bool NT>
+__global__ __launch_bounds__(256) void k_deal(const KArgs a) {
+  using BB = ts::Bitboard<S>;
+  using M = typename BB::mask_t;
+  constexpr int C = BB::C, BPW = kWave / G;
+  constexpr M kFull = C == 64 ? ~M(0) : (M(1) << (C & 63)) - 1;
+  constexpr bool kChunkOnLine = (12 * C * BPW) % 128 == 0;  // a wave's chunk of observation starts on a 128-byte line
+  constexpr int kU8Vec = (3 * C * BPW) % 16 == 0 ? 16 : 4;
+  static_assert(G == 4 || G == 8, "lanes per board");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / G, j = lane & (G - 1);
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece, a.xcd_skew, a.xcd_order) * (blockDim.x >> 6) + wave) * BPW;
+  if (n0 >= a.N) return;  // wave-uniform; no block-level barrier exists in this kernel
+  const int64_t N = a.N;
+  const int64_t n = n0 + g;
+  const bool live = n < N;
+  const int64_t nl = live ? n : N - 1;  // lanes past the batch read the last board and write nothing
+  const int nb = (N - n0) < BPW ? (int)(N - n0) : BPW;
+  const int T = a.T, Tt = a.Tt;
+  const bool mc = a.mc != 0;
+  const uint64_t gmask = ((1ull << G) - 1ull) << (g * G);
+  unsigned char *img = smem + (size_t)wave * a.lds_wave_bytes;   // [BPW][3C] observation bytes
+  unsigned char *tcells = img + a.lds_stage_off;                 // EXTRAS, single-colour reward: target cells [BPW][Tt]
+  unsigned char *ohimg = img + a.lds_oh_off;                     // EXTRAS, one-hot: one piece of the wave's plane stream
+
+  // ---- loads: unconditional, all issued before the first is consumed ----
+  const M blk = load_blk<M>(a.blk, N, nl) & kFull;
+  const bool all_reset = a.op == OP_RESET;  // uniform
+  const uint8_t *cur = all_reset ? a.init : a.pos;
+  int p[TPL], tg[TPL];
+  bool hasT[TPL], hasG[TPL];
+#pragma unroll
+  for (int k = 0; k < TPL; ++k) {
+    const int t = j + k * G;
+    hasT[k] = t < T;
+    hasG[k] = t < Tt;
+    // rows past the count read row 0 of this board (it exists whenever the load is issued)
+    p[k] = T > 0 ? (int)cur[(int64_t)(hasT[k] ? t : 0) * N + nl] : 0;
+    tg[k] = Tt > 0 ? (int)a.tgt[(int64_t)(hasG[k] ? t : 0) * N + nl] : 0;
+  }
+  uint32_t action = 0, done_in = 0;
+  int32_t sc = 0;
+  if (a.op == OP_STEP) {  // uniform
+    done_in = a.done[nl];
+    sc = a.step_count[nl];
+    action = a.actions[nl];
+  }
+  const bool want_obs = a.obs != nullptr || a.obs_u8 != nullptr;
+  if (want_obs) {
+    constexpr int kImg = (BPW * 3 * C + 15) & ~15;
+    for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
+  }
+  int kind;  // 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells (as k_small)
+  uint32_t flags = 0;
+  if (a.op == OP_RESET) {
+    kind = 2;
+  } else if (a.op == OP_OBSERVE) {
+    kind = 1;
+  } else {  // environment.py:113-117
+    kind = done_in ? (a.autoreset ? 2 : 1) : (action > 3 ? 1 : 0);
+    flags = done_in ? (a.autoreset ? TS_FLAG_AUTORESET : TS_FLAG_STEPPED_DONE) : (action > 3 ? TS_FLAG_BAD_ACTION : 0u);
+  }
+  const int dir = (int)(action & 3u);
+  if (kind == 2 && !all_reset) {  // boards that autoreset inside a step: rare
+#pragma unroll
+    for (int k = 0; k < TPL; ++k)
+      if (hasT[k]) p[k] = (int)a.init[(int64_t)(j + k * G) * N + nl];
+  }
+
+  // ---- pre-move occupancy of the whole board: own tiles, then OR over the group ----
+  M occ = 0;
+#pragma unroll
+  for (int k = 0; k < TPL; ++k) {
+    p[k] = min(p[k], C - 1);  // clamp: malformed ids stay in-board
+    tg[k] = min(tg[k], C - 1);
+    occ |= hasT[k] ? M(1) << p[k] : M(0);
+  }
+  occ = group_or<G>(occ);
+
+  // ---- slide (state.py:120-170) ----
+  M occ2 = 0, tgm = 0;
+  bool same = true, ordered = true;
+  const bool store_pos = live && kind != 1;
+#pragma unroll
+  for (int k = 0; k < TPL; ++k) {
+    const int q = kind == 0 ? ts::slide_cell<S>(p[k], occ, blk, dir) : p[k];
+    same &= (q == p[k]) | !hasT[k];
+    ordered &= (q == tg[k]) | !(hasT[k] && hasG[k]);
+    occ2 |= hasT[k] ? M(1) << q : M(0);
+    tgm |= hasG[k] ? M(1) << tg[k] : M(0);
+    if (store_pos && hasT[k]) a.pos[(int64_t)(j + k * G) * N + n] = (uint8_t)q;
+    p[k] = q;
+  }
+  occ2 = group_or<G>(occ2);
+  tgm = group_or<G>(tgm);
+  const bool all_same = (__ballot(same) & gmask) == gmask;
+  const bool all_ordered = (T == Tt) && ((__ballot(ordered) & gmask) == gmask);
+  const bool won = mc ? all_ordered : (occ2 == tgm);  // state.py:172-186
+  if (a.op == OP_OBSERVE && won) flags |= TS_FLAG_IS_WON;  // ts_is_won: no move, just the test
+  if (kind == 0) {
+    if (won) flags |= TS_FLAG_IS_WON | TS_FLAG_SUCCESS;
+    if (all_same) flags |= TS_FLAG_INVALID_MOVE;
+    sc += 1;
+    if (sc >= a.max_steps) flags |= TS_FLAG_TIMEOUT;
+  }
+  if (live && j == 0) {
+    if (kind == 0) {
+      a.step_count[n] = sc;
+      a.done[n] = (uint8_t)((flags & (TS_FLAG_IS_WON | TS_FLAG_TIMEOUT)) != 0);
+    } else if (kind == 2) {
+      a.step_count[n] = 0;
+      a.done[n] = 0;
+    }
+    if (a.flags) a.flags[n] = (uint8_t)flags;
+  }
+
+  if constexpr (EXTRAS) {
+    // ---- legality mask of the post-move board (environment.py:149-171): a free neighbour in the move's direction ----
+    if (a.valid || a.valid4) {
+      const uint32_t vm = ts::valid_mask<S>(occ2, blk);
+      if (live && j == 0 && a.valid) a.valid[n] = (uint8_t)vm;
+      if (live && j == 0 && a.valid4) reinterpret_cast<uint32_t *>(a.valid4)[n] = spread_valid(vm);
+    }
+    // ---- build-defined Manhattan reward (include/tiler_slider.h) ----
+    if (a.reward) {
+      int sum = 0;
+      if (mc) {
+#pragma unroll
+        for (int k = 0; k < TPL; ++k)
+          sum += (hasT[k] && hasG[k]) ? abs(p[k] / S - tg[k] / S) + abs(p[k] % S - tg[k] % S) : 0;
+      } else if (Tt > 0) {
+        unsigned char *tc0 = tcells + (size_t)g * Tt;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k)
+          if (hasG[k]) tc0[j + k * G] = (unsigned char)tg[k];
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+          int best = 1 << 30;
+          for (int t = 0; t < Tt; ++t) {
+            const int y = tc0[t];
+            const int dist = abs(p[k] / S - y / S) + abs(p[k] % S - y % S);
+            best = dist < best ? dist : best;
+          }
+          sum += hasT[k] ? best : 0;
+        }
+      }
+#pragma unroll
+      for (int o = G >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o, kWave);  // stays inside the board's group of lanes
+      if (live && j == 0) a.reward[n] = -sum;
+    }
+  }
+
+  // the obstacle cells this lane drops into the images: those of cells [j * ceil(C / G), (j + 1) * ceil(C / G))
+  constexpr int kShare = (C + G - 1) / G;
+  const int lo_cell = j * kShare;
+  const M my_blk = lo_cell >= C ? M(0) : M((blk >> lo_cell) & ((kShare >= (int)(8 * sizeof(M))) ? ~M(0) : (M(1) << kShare) - 1)) << lo_cell;
+
+  // ---- observation (state.py:188-211) through the LDS byte image ----
+  if (want_obs) {
+    wave_sync();  // the zero fill has landed
+    unsigned char *my = img + g * (3 * C);
+    if (live) {
+      for (M m = my_blk; m; m &= m - 1) my[3 * ts::lsb(m)] = 1;
+#pragma unroll
+      for (int k = 0; k < TPL; ++k)
+        if (hasT[k]) my[3 * p[k] + 1] = (unsigned char)(mc ? j + k * G + 1 : 1);
+#pragma unroll
+      for (int k = 0; k < TPL; ++k)
+        if (hasG[k]) my[3 * tg[k] + 2] = (unsigned char)(mc ? j + k * G + 1 : 1);
+    }
+    const bool dup = mc && live && ts::popc(tgm) != Tt;  // two targets on one cell (never from the factories)
+    if (__ballot(dup) != 0) {
+      // the highest index must win (state.py:209-211), which lanes writing in parallel cannot promise: every lane of a
+      // flagged board raises its targets' bytes until none is below its own index + 1 (each round strictly increases at
+      // least one byte, so the loop ends)
+      for (;;) {
+        wave_sync();
+        bool again = false;
+        if (dup) {
+#pragma unroll
+          for (int k = 0; k < TPL; ++k) {
+            const int t = j + k * G;
+            if (hasG[k] && my[3 * tg[k] + 2] < (unsigned char)(t + 1)) {
+              my[3 * tg[k] + 2] = (unsigned char)(t + 1);
+              again = true;
+            }
+          }
+        }
+        if (__ballot(again) == 0) break;
+      }
+    }
+    wave_sync();
+    if (a.obs) emit_bytes_as_f32<NT, !kChunkOnLine>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+    if (a.obs_u8) emit_bytes_raw<kU8Vec, NT>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
+  }
+
+  // ---- build-defined one-hot planes [board][Ch][S][S]: as k_lines, 8 KiB pieces of the wave's stream ----
+  if constexpr (EXTRAS) {
+    if (a.onehot) {
+      constexpr int kOhPiece = 8192;
+      const int Ch = a.onehot_ch;
+      const int64_t D = (int64_t)Ch * C;          // floats per board
+      const int64_t total = (int64_t)nb * D;      // floats of this wave
+      const int64_t mine = (int64_t)g * D;        // where this lane's board starts in the stream
+      float *dst = a.onehot + n0 * D;
+      for (int64_t p0 = 0; p0 < total; p0 += kOhPiece) {
+        wave_sync();  // the previous piece has been read out
+        for (int off = lane * 16; off < kOhPiece; off += kWave * 16) *reinterpret_cast<uint4 *>(ohimg + off) = make_uint4(0, 0, 0, 0);
+        wave_sync();
+        auto drop = [&](int plane, int cell) {
+          const int64_t e = mine + (int64_t)plane * C + cell - p0;
+          if (e >= 0 && e < kOhPiece) ohimg[e] = 1;
+        };
+        if (live) {
+          for (M m = my_blk; m; m &= m - 1) drop(0, ts::lsb(m));
+#pragma unroll
+          for (int k = 0; k < TPL; ++k) {
+            if (hasT[k]) drop(mc ? 1 + j + k * G : 1, p[k]);
+            if (hasG[k]) drop(mc ? 1 + T + j + k * G : 2, tg[k]);
+          }
+        }
+        wave_sync();
+        const int64_t left = total - p0;
+        emit_bytes_as_f32<NT, true>(ohimg, dst + p0, (int)(left < kOhPiece ? left : kOhPiece), lane, a.emit_edges);
+      }
+    }
   }
 }
 
@@ -1054,7 +1314,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   const int wave = threadIdx.x >> 6;
   const int g = lane / G, j = lane & (G - 1);
   const int bpw = (int)a.bpw;  // boards per wave: 64 / LPB (or fewer: the upper lanes idle)
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece) * (blockDim.x >> 6) + wave) * bpw;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece, a.xcd_skew, a.xcd_order) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform
   const int64_t N = a.N;
   const int64_t n = n0 + g;
@@ -1170,7 +1430,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   bool same = true, ordered = true;
   cell_t *pos_out = reinterpret_cast<cell_t *>(a.pos) + off0;
   const bool store_pos = live && kind != 1;
-  const bool need_rows = !mc || (EXTRAS && a.valid != nullptr);  // post-move row masks
+  const bool need_rows = !mc || (EXTRAS && (a.valid != nullptr || a.valid4 != nullptr));  // post-move row masks
 #pragma unroll
   for (int k = 0; k < TPL; ++k) {
     const int line = vert ? pc[k] : pr[k];
@@ -1237,7 +1497,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
     // obstacle / the wall and every other tile touches a tile; conversely a tile with a free
     // neighbour sits in a run that is not packed.  So four neighbour tests per tile replace four
     // trial slides; tests/: every shape against the oracle's four trial moves.
-    if (a.valid) {
+    if (a.valid || a.valid4) {
       uint32_t mv = 0;
 #pragma unroll
       for (int k = 0; k < TPL; ++k) {
@@ -1254,7 +1514,8 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
       uint32_t vm = 0;
 #pragma unroll
       for (int d = 0; d < 4; ++d) vm |= ((__ballot((mv >> d) & 1u) & gmask) != 0 ? 1u : 0u) << d;
-      if (live && j == 0) a.valid[n] = (uint8_t)vm;
+      if (live && j == 0 && a.valid) a.valid[n] = (uint8_t)vm;
+      if (live && j == 0 && a.valid4) reinterpret_cast<uint32_t *>(a.valid4)[n] = spread_valid(vm);
     }
     // ---- build-defined Manhattan reward (include/tiler_slider.h) ----
     if (a.reward) {
@@ -1573,6 +1834,8 @@ std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_T
 std::atomic<int64_t> g_lines_lanes{0};  // ts_tuning(TS_TUNE_LINES_LANES): 0 = by tile count, 4 / 8 / 16 = forced where instantiated
 std::atomic<int64_t> g_lines_bpw{0};    // ts_tuning(TS_TUNE_LINES_BPW): 0 = policy, else boards per wave of k_lines (the other lanes idle)
 std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): INT64_MAX = policy, 0 = eighths, P = pieces of P blocks (out-of-cache launches)
+std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
+std::atomic<int64_t> g_xcd_skew{0}, g_xcd_order{0};  // ts_tuning(TS_TUNE_XCD_SKEW / TS_TUNE_XCD_ORDER): experiments (round 4)
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
 std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
 
@@ -1663,10 +1926,41 @@ bool multi_applicable(const KArgs &a) {
   if (a.N % (int64_t)G != 0 || a.N < g_multi_min_boards.load(std::memory_order_relaxed) || a.nt || a.onehot) return false;
   const uintptr_t bytes = (uintptr_t)a.pos | (uintptr_t)a.init | (uintptr_t)a.tgt | (uintptr_t)a.done | (uintptr_t)a.actions |
                           (uintptr_t)a.flags | (uintptr_t)a.valid;
+  if ((uintptr_t)a.valid4 & (4 * G - 1)) return false;
   const uintptr_t words = (uintptr_t)a.blk | (uintptr_t)a.step_count | (uintptr_t)a.reward;
   return (bytes & (G - 1)) == 0 && (words & (4 * G - 1)) == 0;
 }
 #endif
+
+// k_deal: boards up to 8x8 with 9 .. 64 tiles (and targets), G lanes per board, TPL tiles per lane
+template <int S, bool EXTRAS, bool NT>
+SmallKernel deal_kernel_for(int lanes, int tpl) {
+  if constexpr (S < 4) {
+    return nullptr;
+  } else {
+    if (lanes == 4) return tpl == 4 ? k_deal<S, 4, 4, EXTRAS, NT> : nullptr;
+    if (tpl == 2) return k_deal<S, 8, 2, EXTRAS, NT>;
+    if constexpr (S >= 5) {
+      if (tpl == 4) return k_deal<S, 8, 4, EXTRAS, NT>;
+    }
+    if constexpr (S >= 6) {
+      if (tpl == 8) return k_deal<S, 8, 8, EXTRAS, NT>;
+    }
+    return nullptr;
+  }
+}
+
+template <bool EXTRAS, bool NT>
+SmallKernel deal_kernel(int S, int lanes, int tpl) {
+  switch (S) {
+    case 4: return deal_kernel_for<4, EXTRAS, NT>(lanes, tpl);
+    case 5: return deal_kernel_for<5, EXTRAS, NT>(lanes, tpl);
+    case 6: return deal_kernel_for<6, EXTRAS, NT>(lanes, tpl);
+    case 7: return deal_kernel_for<7, EXTRAS, NT>(lanes, tpl);
+    case 8: return deal_kernel_for<8, EXTRAS, NT>(lanes, tpl);
+    default: return nullptr;
+  }
+}
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
@@ -1807,6 +2101,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   if ((a.op == OP_RESET || (a.op == OP_STEP && a.autoreset)) && T && !st->init) return TS_ERR_NULL;
   if (a.op != OP_OBSERVE && (!st->step_count || !st->done)) return TS_ERR_NULL;
   if (((uintptr_t)a.obs & 15u) || ((uintptr_t)a.onehot & 15u) || ((uintptr_t)a.obs_u8 & 15u)) return TS_ERR_ARG;  // 16-B stores
+  if ((uintptr_t)a.valid4 & 3u) return TS_ERR_ARG;  // one 32-bit store per board
   a.pos = static_cast<uint8_t *>(st->pos);  // k_lines reinterprets these as uint16 above 16x16
   a.init = static_cast<const uint8_t *>(st->init);
   a.tgt = static_cast<const uint8_t *>(st->tgt);
@@ -1829,6 +2124,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                   : piece <= 0x7fffffff ? (uint32_t)piece : 0xffffffffu;  // 0xffffffff: by kernel, below
     const int64_t forced = g_emit_edges.load(std::memory_order_relaxed);
     a.emit_edges = d->emit_edges > 0 ? (uint32_t)(d->emit_edges - 1) : forced >= 0 && forced <= 3 ? (uint32_t)forced : 0xffu;  // 0xff: by shape, below
+    a.xcd_skew = (uint32_t)g_xcd_skew.load(std::memory_order_relaxed);
+    a.xcd_order = (uint32_t)g_xcd_order.load(std::memory_order_relaxed);
   }
   hipStream_t hs = (hipStream_t)stream;
 
@@ -1840,7 +2137,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     }
 #if TS_MULTI_G > 0
     if (S >= 2 && S <= 5 && tfix > 0 && multi_applicable(a)) {  // cache-resident: G boards per lane
-      const bool extras = a.valid || a.reward;
+      const bool extras = a.valid || a.valid4 || a.reward;
       SmallKernel k = extras ? multi_kernel<true>(S, tfix) : multi_kernel<false>(S, tfix);
       a.lds_wave_bytes = (a.obs || a.obs_u8) ? align16((uint32_t)(kWave * TS_MULTI_G * 3 * C)) : 0u;
       a.bpw = kWave * TS_MULTI_G;
@@ -1852,6 +2149,39 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
       return finish_launch();
     }
 #endif
+    const int maxT = T > Tt ? T : Tt;
+    if (tfix == 0 && S >= 4 && maxT > 8 && maxT <= 64 && g_deal_enabled.load(std::memory_order_relaxed) != 0) {
+      // more than 8 tiles: a board's tiles dealt over 4 or 8 lanes (k_deal); ts_dims.lines_lanes / TS_TUNE_LINES_LANES force 4 or 8
+      int lanes = maxT <= 16 ? TS_DEAL_LANES_SMALL : 8;
+      if (const int64_t forced = g_lines_lanes.load(std::memory_order_relaxed); forced == 4 || forced == 8) lanes = (int)forced;
+      if (d->lines_lanes == 4 || d->lines_lanes == 8) lanes = d->lines_lanes;
+      if (maxT > 16) lanes = 8;
+      const int tpl = lanes == 4 ? 4 : maxT <= 16 ? 2 : maxT <= 32 ? 4 : 8;
+      const bool extras = a.valid || a.valid4 || a.reward || a.onehot;
+      SmallKernel k = extras ? (a.nt ? deal_kernel<true, true>(S, lanes, tpl) : deal_kernel<true, false>(S, lanes, tpl))
+                             : (a.nt ? deal_kernel<false, true>(S, lanes, tpl) : deal_kernel<false, false>(S, lanes, tpl));
+      if (k) {
+        const int bpw = kWave / lanes;
+        a.oh_boards = 0;
+        a.bpw = (uint32_t)bpw;
+        a.lds_stage_off = align16((uint32_t)(bpw * 3 * C));
+        a.lds_oh_off = align16(a.lds_stage_off + ((a.reward && !d->multi_color) ? (uint32_t)(bpw * Tt) : 0u));
+        a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u);
+        const uint64_t out_pb = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
+        Residency res = ooc_residency(a.nt != 0, true, false, (uint64_t)bpw * out_pb, T);
+        apply_launch_hint(res, d->launch_hint);
+        if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
+        if (a.xcd_piece == 0xffffffffu) a.xcd_piece = 0u;
+        int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
+        while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
+        const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
+        const int64_t boards_per_block = (int64_t)waves * bpw;
+        const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
+        if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a);
+        return finish_launch();
+      }
+    }
     const bool need_masks = a.onehot && !a.oh_boards;
     const bool need_stage = tfix == 0 || need_masks;
     a.lds_stage_off = align16((uint32_t)(small_obs_boards(C, tfix == 0) * 3 * C));
@@ -1872,7 +2202,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const int64_t boards_per_block = (int64_t)waves * a.bpw;
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-    const bool extras = a.valid || a.reward || a.onehot;
+    const bool extras = a.valid || a.valid4 || a.reward || a.onehot;
     SmallKernel k = extras ? (a.nt ? small_kernel<true, true>(S, tfix) : small_kernel<true, false>(S, tfix))
                            : (a.nt ? small_kernel<false, true>(S, tfix) : small_kernel<false, false>(S, tfix));
 #if TS_SET_LDS_ATTR
@@ -1903,7 +2233,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     while (tpl < per_lane) tpl <<= 1;
     const int nln = wide ? 32 : 16;
     a.lds_stage_off = align16((uint32_t)(bpw_max * 3 * C));
-    const bool lines_extras = a.valid || a.reward || a.onehot;
+    const bool lines_extras = a.valid || a.valid4 || a.reward || a.onehot;
     a.lds_oh_off = a.lds_stage_off + (uint32_t)(bpw_max * nln * ((wide ? 2 : 1) + 1 + 1) * 4) +
                    (a.reward && !d->multi_color ? align16((uint32_t)(bpw_max * Tt * 2)) : 0u);
     a.lds_wave_bytes = align16(a.lds_oh_off) + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
@@ -2014,6 +2344,7 @@ int32_t ts_step(const ts_dims *dims, const ts_state *st, const uint8_t *actions,
   a.reward = out->reward;
   a.onehot = out->onehot;
   a.valid = out->valid;
+  a.valid4 = out->valid4;
   a.obs_u8 = out->obs_u8;
   return launch(dims, st, a, stream);
 }
@@ -2026,6 +2357,17 @@ int32_t ts_valid_moves(const ts_dims *dims, const ts_state *st, uint8_t *mask, v
   KArgs a = {};
   a.op = OP_OBSERVE;
   a.valid = mask;
+  return launch(dims, st, a, stream);
+}
+
+int32_t ts_valid_moves4(const ts_dims *dims, const ts_state *st, uint8_t *mask4, void *stream) {
+  const int32_t rc = check_dims(dims);
+  if (rc) return rc;
+  if (dims->n_boards == 0) return TS_OK;  // an empty batch may carry NULL buffers
+  if (!st || !mask4) return TS_ERR_NULL;
+  KArgs a = {};
+  a.op = OP_OBSERVE;
+  a.valid4 = mask4;
   return launch(dims, st, a, stream);
 }
 
@@ -2117,7 +2459,10 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_LINES_LANES ? &g_lines_lanes
                                : key == TS_TUNE_LINES_BPW ? &g_lines_bpw
                                : key == TS_TUNE_EMIT_EDGES ? &g_emit_edges
-                               : key == TS_TUNE_XCD_PIECE ? &g_xcd_piece : nullptr;
+                               : key == TS_TUNE_XCD_PIECE ? &g_xcd_piece
+                               : key == TS_TUNE_XCD_SKEW ? &g_xcd_skew
+                               : key == TS_TUNE_XCD_ORDER ? &g_xcd_order
+                               : key == TS_TUNE_DEAL ? &g_deal_enabled : nullptr;
   if (!knob) return -1;
   return value >= 0 ? knob->exchange(value) : knob->load();
 }

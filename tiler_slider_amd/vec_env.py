@@ -263,6 +263,8 @@ class VecTilerSliderEnv:
         self._onehot = (self._big_zeros((N, self.onehot_channels, self.size, self.size), torch.float32)
                         if with_onehot else None)
         self._valid = self._zeros(N, torch.uint8) if with_valid_moves else None
+        # the same mask in the reference's shape, written by the step kernel itself: uint8 [N, 4] of 0 / 1, viewed as bool
+        self._valid4 = self._zeros((N, 4), torch.uint8) if with_valid_moves else None
         # per-level tables of the large-board kernel (include/tiler_slider.h: ts_prepare): the level
         # never changes during an episode, so they are built once, here
         lw = L.ts_lines_words(self.size)
@@ -284,7 +286,8 @@ class VecTilerSliderEnv:
     def _bind_outputs(self):
         f32 = self.obs_dtype == torch.float32
         self._outs = [_cabi.StepOut(_ptr(self._flags), _ptr(o) if f32 else None, _ptr(self._reward),
-                                    _ptr(self._onehot), _ptr(self._valid), None if f32 else _ptr(o)) for o in self._obs_ring]
+                                    _ptr(self._onehot), _ptr(self._valid), None if f32 else _ptr(o), _ptr(self._valid4))
+                      for o in self._obs_ring]
         self._obs_slot = 0
         self._obs = self._obs_ring[0]
         self._out = self._outs[0]
@@ -372,7 +375,7 @@ class VecTilerSliderEnv:
         if self._onehot is not None:
             self._onehot.zero_()
         self._pos.copy_(saved[0]), self._step_count.copy_(saved[1]), self._done.copy_(saved[2]), self._flags.copy_(saved[3])
-        for t in (self._reward, self._valid):
+        for t in (self._reward, self._valid, self._valid4):
             if t is not None:
                 t.zero_()
         self._bind_outputs()
@@ -488,14 +491,16 @@ class VecTilerSliderEnv:
         return graph
 
     def get_valid_moves(self):
-        """bool [N, 4]: column d is True where Move(d) would change the board."""
+        """bool [N, 4]: column d is True where Move(d) would change the board (one launch: the kernel writes the
+        0 / 1 rows itself, ts_valid_moves4; the bool tensor is a view of them)."""
         self._require_open()
-        mask = self._empty(self.num_envs, torch.uint8)
+        mask4 = self._empty((self.num_envs, 4), torch.uint8)
         if not self._started:  # environment.py:156-157: [] before reset
-            return torch.zeros((self.num_envs, 4), dtype=torch.bool, device=mask.device)
-        self._call("ts_valid_moves", C.byref(self._dims), C.byref(self._state), mask.data_ptr())
+            return torch.zeros((self.num_envs, 4), dtype=torch.bool, device=mask4.device)
+        if self.num_envs:
+            self._call("ts_valid_moves4", C.byref(self._dims), C.byref(self._state), mask4.data_ptr())
         self._sync_if_host()
-        return _expand_mask(mask)
+        return mask4.view(torch.bool)
 
     def valid_move_bits(self, out=None):
         """uint8 [N]: bit d set where Move(d) would change the board — the kernel's raw output,
@@ -571,7 +576,7 @@ class VecTilerSliderEnv:
         if self._onehot is not None:
             extras["onehot"] = self._onehot
         if self._valid is not None:
-            extras["valid_moves"] = _expand_mask(self._valid)
+            extras["valid_moves"] = self._valid4.view(torch.bool)
         return StepInfo(self._flags, self._step_count, extras)
 
     def _stage_actions(self, actions):
@@ -684,7 +689,3 @@ def _to_device(a, dtype, device):
 def _ptr(t):
     return None if t is None or t.numel() == 0 else t.data_ptr()
 
-
-def _expand_mask(mask):
-    shifts = torch.arange(4, device=mask.device, dtype=torch.uint8)
-    return ((mask[:, None] >> shifts[None, :]) & 1).to(torch.bool)
