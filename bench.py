@@ -171,17 +171,19 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the timed steps from one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
-    ap.add_argument("--placement-trials", type=int, default=6,
+    ap.add_argument("--placement-trials", type=int, default=0,
                     help="VecTilerSliderEnv(placement_trials=...) for batches beyond the Infinity Cache: 0 = the library's static "
-                         "launch policy, 1 = launch policy rated at construction on the first allocation (the class default), "
+                         "launch policy (the class default), 1 = launch policy rated at construction on the first allocation, "
                          "k > 1 = also up to k candidate allocations of the output buffers (reported in config)")
     ap.add_argument("--policy", default=None,
                     help="launch_hint,emit_edges,lines_lanes,xcd_piece: fix the per-call launch policy of ts_dims (use with --placement-trials 0 "
                          "to profile exactly the launches a tuned run settled on)")
-    ap.add_argument("--output-memory", choices=["torch", "contiguous"], default="torch",
+    ap.add_argument("--output-memory", choices=["torch", "contiguous"], default="contiguous",
                     help="VecTilerSliderEnv(output_memory=...): physically contiguous output buffers beyond the Infinity Cache, or torch's allocator")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-halves-on-two-streams figure")
     ap.add_argument("--no-sibling", action="store_true", help="skip the out-of-cache sibling of a cache-resident config")
+    ap.add_argument("--no-entry-points", action="store_true", help="skip reset / scramble / stand-alone entry-point timings")
+    ap.add_argument("--no-learner-side", action="store_true", help="skip the cfg3 learner-side timings (8,388,608 gathered boards)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short timings of the other single-GPU BASELINE configs (cfg2, cfg4) that a cfg1 run appends")
     ap.add_argument("--compact-u8", action="store_true",
@@ -269,8 +271,12 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
 
     tm = torch.tensor([wall, dev_ms], dtype=torch.float64, device=device)
+    rccl_ranks = None
     if multi:
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ones = torch.ones(1, dtype=torch.int32, device=device)  # how many ranks the collective library itself saw
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_ranks = int(ones[0])
     wall, dev_ms = float(tm[0]), float(tm[1])
     total_boards = n * world
     value = total_boards * args.steps / wall
@@ -393,6 +399,18 @@ def main():
         del pe, pacts
         torch.cuda.empty_cache()
 
+    # reset() and the "scramble" (the reference's own seed -> level map on the device, ts_generate_mt19937) of this batch
+    extras_us = None
+    if world == 1 and not args.no_entry_points:
+        extras_us = time_entry_points(env, cfg, device, L, stream)
+
+    # cfg3 (8 x 1,048,576 boards, one learner): what the learner GPU does per step after a compact / uint8 all-gather, at the
+    # FULL gathered size - one ts_encode over 8,388,608 boards and one ts_expand_u8 over their 403 MB of bytes (1.6 GB out)
+    learner = None
+    if world == 1 and args.config == "cfg1" and not args.boards and not args.no_learner_side:
+        learner = time_learner_side(cfg, 8 * n, device, L, stream)
+        torch.cuda.empty_cache()
+
     gather = None
     if multi and not args.no_gather:
         gather = time_gathers(env, ring, world, n, dist, torch, device, min(args.steps, 20))
@@ -451,6 +469,12 @@ def main():
             line["compact_u8_obs"] = compact
         if gather is not None:
             line["allgather"] = gather
+        if rccl_ranks is not None:
+            line["rccl_ranks"] = rccl_ranks  # all_reduce(SUM) of one 1 per rank over the "nccl" (= RCCL) group
+        if extras_us is not None:
+            line["entry_points"] = extras_us
+        if learner is not None:
+            line["cfg3_learner_side"] = learner
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         # libraries write to the process's stdout on their own (RCCL prints a version banner when the first
@@ -461,6 +485,100 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _event_us(torch, fn, reps, rounds=3):
+    import statistics
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(rounds):
+        fn()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+    return statistics.median(ts)
+
+
+def time_entry_points(env, cfg, device, L, stream):
+    """HIP-event times (us per call, C-ABI launches only, outputs preallocated) of reset(), the scramble and the stand-alone
+    entry points on the bench batch, each with its own algorithmic bytes and fraction of the HBM peak."""
+    import ctypes as C
+    import torch
+    from tiler_slider_amd import _cabi
+    n, S, T = env.num_envs, env.size, env.n_tiles
+    Cc = S * S
+    blk_b = 2 if Cc <= 16 else 4 * ((Cc + 31) // 32)
+    state_read = 2 * T + blk_b
+    d, st = env._dims, env._state
+    obs = torch.empty_like(env._obs)
+    m1, m4 = torch.empty(n, dtype=torch.uint8, device=device), torch.empty((n, 4), dtype=torch.uint8, device=device)
+    rw = torch.empty(n, dtype=torch.int32, device=device)
+    seeds = torch.arange(n, dtype=torch.int64, device=device).to(torch.int32)
+    lv = [torch.zeros_like(env._blk), torch.zeros_like(env._init), torch.zeros_like(env._tgt)]
+    gen_st = _cabi.State(None, lv[1].data_ptr(), lv[2].data_ptr(), lv[0].data_ptr(), None, None, None)
+    saved = (env._pos.clone(), env._step_count.clone(), env._done.clone())
+    calls = {
+        # name: (callable, algorithmic bytes per board)
+        "ts_reset": (lambda: L.ts_reset(C.byref(d), C.byref(st), obs.data_ptr(), stream), T + blk_b + T + T + 4 + 1 + 12 * Cc),
+        "ts_encode": (lambda: L.ts_encode(C.byref(d), C.byref(st), obs.data_ptr(), stream), state_read + 12 * Cc),
+        "ts_valid_moves": (lambda: L.ts_valid_moves(C.byref(d), C.byref(st), m1.data_ptr(), stream), T + blk_b + 1),
+        "ts_valid_moves4": (lambda: L.ts_valid_moves4(C.byref(d), C.byref(st), m4.data_ptr(), stream), T + blk_b + 4),
+        "ts_is_won": (lambda: L.ts_is_won(C.byref(d), C.byref(st), m1.data_ptr(), stream), 2 * T + 1),
+        "ts_reward": (lambda: L.ts_reward(C.byref(d), C.byref(st), rw.data_ptr(), stream), 2 * T + 4),
+        "ts_generate_mt19937": (lambda: L.ts_generate_mt19937(C.byref(d), C.byref(gen_st), seeds.data_ptr(), cfg["obstacles"], stream),
+                                4 + 2 * T + blk_b),
+    }
+    out = {}
+    for name, (fn, bpb) in calls.items():
+        us = _event_us(torch, fn, 3 if name == "ts_generate_mt19937" else 20)
+        out[name] = {"us": us, "algorithmic_bytes_per_board": bpb, "achieved_GBps": bpb * n / us / 1e3,
+                     "frac": bpb * n / us / 1e3 / HBM_PEAK_GBS}
+    t0 = time.perf_counter()
+    for _ in range(20):
+        env.get_valid_moves()
+    torch.cuda.synchronize(device)
+    out["get_valid_moves_python"] = {"us": (time.perf_counter() - t0) * 1e6 / 20,
+                                     "note": "VecTilerSliderEnv.get_valid_moves(): allocation + one ts_valid_moves4 launch + bool view, wall clock"}
+    env._pos.copy_(saved[0]), env._step_count.copy_(saved[1]), env._done.copy_(saved[2])
+    out["reset_us"], out["scramble_us"] = out["ts_reset"]["us"], out["ts_generate_mt19937"]["us"]
+    out["boards"] = n
+    return out
+
+
+def time_learner_side(cfg, n_all, device, L, stream):
+    """One ts_encode over all gathered boards (after the compact all-gather) and one ts_expand_u8 over all gathered byte
+    observations (after the uint8 all-gather), at the full cfg3 size, on one GPU."""
+    import ctypes as C
+    import torch
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    S, T = cfg["size"], cfg["tiles"]
+    Cc = S * S
+    env = VecTilerSliderEnv.random(n_all, size=S, num_tiles=T, num_obstacles=cfg["obstacles"], seed=LEVEL_SEED, multi_color=True,
+                                   max_steps=2**30, device=device, placement_trials=0, obs_dtype="uint8")
+    u8 = env.reset()                                        # uint8 [n_all, S, S, 3]: what the uint8 all-gather delivers
+    from tiler_slider_amd.vec_env import _contiguous_zeros
+    out = _contiguous_zeros((n_all, S, S, 3), torch.float32, device)  # the learner's buffer: physically contiguous, as the environments' own
+    if out is None:
+        out = torch.empty((n_all, S, S, 3), dtype=torch.float32, device=device)
+    d, st = env._dims, env._state
+    enc_us = _event_us(torch, lambda: L.ts_encode(C.byref(d), C.byref(st), out.data_ptr(), stream), 10)
+    exp_us = _event_us(torch, lambda: L.ts_expand_u8(u8.data_ptr(), out.data_ptr(), u8.numel(), stream), 10)
+    ok = None
+    if n_all <= (1 << 23):  # the two hand-offs deliver the same tensor: ts_encode(cells) == float(ts_encode_u8 bytes)
+        L.ts_encode(C.byref(d), C.byref(st), out.data_ptr(), stream)
+        ok = bool(torch.equal(out, u8.to(torch.float32)))
+    enc_b = (2 * T + (2 if Cc <= 16 else 4 * ((Cc + 31) // 32)) + 12 * Cc) * n_all
+    exp_b = 15 * Cc * n_all
+    res = {"boards": n_all, "encode_us": enc_us, "expand_us": exp_us,
+           "encode": {"algorithmic_bytes": enc_b, "achieved_GBps": enc_b / enc_us / 1e3, "frac": enc_b / enc_us / 1e3 / HBM_PEAK_GBS},
+           "expand": {"algorithmic_bytes": exp_b, "achieved_GBps": exp_b / exp_us / 1e3, "frac": exp_b / exp_us / 1e3 / HBM_PEAK_GBS},
+           "frac": min(enc_b / enc_us, exp_b / exp_us) / 1e3 / HBM_PEAK_GBS, "expand_equals_encode": ok,
+           "note": "learner GPU of cfg3: ts_encode over 8 x 1,048,576 gathered boards / ts_expand_u8 over their byte observations"}
+    del env, out, u8
+    return res
 
 
 def time_config(name, trials, steps, device, L, stream):
@@ -479,18 +597,19 @@ def time_config(name, trials, steps, device, L, stream):
                        + (", + one-hot + Manhattan reward" if cfg["onehot"] else ""),
            "kernel": dominant_kernel(cfg, n, L), "algorithmic_bytes_per_board_step": bps, "algorithmic_bytes_per_launch": bps * n,
            "steps": steps}
-    # library_policy: static launch policy, no measuring at construction; first_allocation: the class default (launch policy
-    # rated at construction on the buffers first allocated); tuned: + candidate buffers; *_contiguous_memory: the class default
-    # with the output buffers in physically contiguous memory (output_memory="contiguous": the same speed every time)
-    for key, k, mem in (("library_policy", 0, "torch"), ("first_allocation", 1, "torch"), ("tuned", trials, "torch"),
-                        ("first_allocation_contiguous_memory", 1, "contiguous")):
+    # first_allocation_contiguous_memory: THE CLASS DEFAULT - output buffers in physically contiguous memory, the library's
+    # static launch policy, nothing measured at construction (placement_trials = 0): the same in every process;
+    # torch_allocator: the same policy on buffers from torch's caching allocator (one of two speeds, by allocation);
+    # torch_allocator_rated: + launch policy rated at construction on those buffers; tuned: + candidate buffers (opt-in)
+    for key, k, mem in (("first_allocation_contiguous_memory", 0, "contiguous"), ("torch_allocator", 0, "torch"),
+                        ("torch_allocator_rated", 1, "torch"), ("tuned", trials, "torch")):
         if key == "tuned" and trials <= 1:
             continue
         env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"], seed=LEVEL_SEED,
                                        multi_color=True, max_steps=2**30, device=device, auto_reset=True, with_reward=cfg["reward"],
                                        with_onehot=cfg["onehot"], placement_trials=k, output_memory=mem)
         env.reset()
-        for i in range(10):
+        for i in range(50):
             env.step_async(acts[i & 3])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -500,7 +619,7 @@ def time_config(name, trials, steps, device, L, stream):
         torch.cuda.synchronize(device)
         us = e0.elapsed_time(e1) * 1e3 / steps
         gbs = bps * n / us / 1e3
-        out[key] = {"placement_trials": k, "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s", "achieved": gbs,
+        out[key] = {"placement_trials": k, "output_memory": mem, "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s", "achieved": gbs,
                     "achieved_unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS,
                     "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges, "lines_lanes": env._dims.lines_lanes, "xcd_piece": env._dims.xcd_piece},
                     "placement": env.placement_report}

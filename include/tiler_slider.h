@@ -264,11 +264,13 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
 #define TS_TUNE_LINES_BPW 3
 #define TS_TUNE_EMIT_EDGES 4
 #define TS_TUNE_XCD_PIECE 5
-#define TS_TUNE_XCD_SKEW 6  /* experiment (round 4): XCD x starts x * value blocks into its range / piece; default 0 */
-#define TS_TUNE_XCD_ORDER 7 /* experiment (round 4): order of the blocks inside a piece: 0 ascending, 1 bit-reversed, 2 descending */
-#define TS_TUNE_DEAL 8      /* 1 (default): boards up to 8x8 with 9 .. 64 tiles run with a board's tiles dealt over 4 or 8 lanes
+#define TS_TUNE_DEAL 6      /* 1 (default): boards up to 8x8 with 9 .. 64 tiles run with a board's tiles dealt over 4 or 8 lanes
                              * (k_deal; TS_TUNE_LINES_LANES / ts_dims.lines_lanes = 4 or 8 choose for 9 .. 16 tiles); 0: one lane
                              * per board as for any other tile count (k_small), kept for A/B and as the parity cross-check */
+#define TS_TUNE_MT_WINDOW 7 /* ts_generate_mt19937 on boards up to 10x10 streams the generator's first outputs from the seeding
+                             * recurrence without building its 624-word state; a seed that needs more than `value` outputs
+                             * (default and maximum 227) takes the general form.  0 = always the general form.  Results never
+                             * differ; tests shrink the window to exercise the hand-over. */
 int64_t ts_tuning(int32_t key, int64_t value);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */

@@ -97,9 +97,18 @@ def _worker(rank, world, port, case, q):
         ok &= torch.equal(a, whole._obs) and torch.equal(b, whole._obs) and torch.equal(c, whole._obs)
         # the async forms: a handle now, the assembled tensor at wait()
         ha = g.gather_observations(env._obs, async_op=True)
+        # ONE gather in flight per gatherer (its receive side is single-buffered): a second one - of any form, sync or
+        # async - is refused before it touches a buffer, on every rank alike (no collective is issued)
+        for second in (lambda: g.gather_compact_and_encode(async_op=True), lambda: g.gather_observations()):
+            try:
+                second()
+                ok = False
+            except RuntimeError as e:
+                ok &= "still in flight" in str(e)
+        hc = g8.gather_u8_and_expand(async_op=True)  # another gatherer is independent
+        ok &= torch.equal(ha.wait(), whole._obs) and ha.finished
         hb = g.gather_compact_and_encode(async_op=True)
-        hc = g8.gather_u8_and_expand(async_op=True)
-        ok &= torch.equal(ha.wait(), whole._obs) and torch.equal(hb.wait().clone(), whole._obs)
+        ok &= torch.equal(hb.wait().clone(), whole._obs)
         ok &= torch.equal(hc.wait(), whole._obs) and ha.wait() is g.obs_all  # wait() is idempotent
         # the compact hand-off sends a SNAPSHOT of the cell ids: stepping before wait() must not change what arrives
         # (the pre-fix code sent env._pos itself, which the next step rewrites in place)

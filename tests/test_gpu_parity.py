@@ -1025,3 +1025,19 @@ def test_pipelined_parts_equal_one_environment(torch_cuda, oracle):
         env.close()
     with pytest.raises(ValueError):
         PipelinedTilerSliderEnv(1001, parts=2, **kw)
+
+
+def test_main_entry_point_plays_the_cfg0_board(torch_cuda, capsys):
+    """BASELINE.json configs[0]: one 3x3 board with one tile through main.py (the reference's main.py:1-6 only prints a
+    greeting; this one plays the moves through the reference-compatible single-board API, on the GPU)."""
+    import main
+    assert main.main(["main.py", "DR"]) == 0
+    out = capsys.readouterr().out
+    assert "Initial state:\nStep: 0/100\nDone: False\n\na..\n...\n..A" in out          # display.py:63-75 precedence
+    assert "Move 1: DOWN\nStep: 1/100\nDone: False\n\n...\n...\na.A" in out
+    assert "Move 2: RIGHT\nStep: 2/100\nDone: True\n\n...\n...\n..A" in out            # the tile under its target prints as the target
+    assert "Puzzle solved!" in out and out.rstrip().endswith("solved in 2 steps")
+    assert main.main(["main.py", "R"]) == 1                                               # one move does not solve it
+    assert capsys.readouterr().out.rstrip().endswith("not solved in 1 steps")
+    with pytest.raises(SystemExit):
+        main.main(["main.py", "DXR"])

@@ -101,3 +101,27 @@ def test_hip_generator_survey_captures_and_scale():
         b, i, t = numpy_level(5, 2, 3, n)
         assert unpack(5, env._blk[:, n:n + 1].cpu().numpy().view(np.uint32), env._init[:, n:n + 1].cpu().numpy(),
                       env._tgt[:, n:n + 1].cpu().numpy(), 0) == (set(b), i, t)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window", [0, 3, 24, 90, 227])
+def test_streamed_generator_hands_over_to_the_general_form(oracle, window):
+    """Boards up to 10x10 stream the generator's first outputs from the seeding recurrence (no 624-word state); a seed that
+    needs more outputs than the window takes the general form.  With shrunken windows some / most / all seeds of a batch
+    hand over - the levels must not change (TS_TUNE_MT_WINDOW)."""
+    import torch
+    from tiler_slider_amd import TilerSliderEnvFactory, _cabi
+    L = _cabi.lib()
+    before = L.ts_tuning(_cabi.TUNE_MT_WINDOW, window)
+    try:
+        assert before == 227 and L.ts_tuning(_cabi.TUNE_MT_WINDOW, -1) == window
+        for index, (size, T, K) in enumerate([(2, 1, 1), (4, 2, 2), (5, 2, 3), (8, 20, 10), (10, 5, 5), (10, 40, 20)]):
+            seeds = seeds_for(50 + index, 3000)
+            env = TilerSliderEnvFactory.create_vec_env_from_seeds(seeds, size=size, num_tiles=T, num_obstacles=K)
+            blk, init, tgt = oracle.generate_mt19937(size, T, T, K, seeds)
+            np.testing.assert_array_equal(env._blk.cpu().numpy().view(np.uint32), blk)
+            np.testing.assert_array_equal(env._init.cpu().numpy().astype(np.int64), init.astype(np.int64))
+            np.testing.assert_array_equal(env._tgt.cpu().numpy().astype(np.int64), tgt.astype(np.int64))
+    finally:
+        L.ts_tuning(_cabi.TUNE_MT_WINDOW, before)
+    assert L.ts_tuning(_cabi.TUNE_MT_WINDOW, 1000) == 227 and L.ts_tuning(_cabi.TUNE_MT_WINDOW, -1) == 227  # clamped

@@ -86,6 +86,12 @@
 #ifndef TS_XCD_PIECE_POLICY  // out-of-cache launches with short chunks per wave: pieces of P blocks per XCD (piece_policy)
 #define TS_XCD_PIECE_POLICY 64
 #endif
+#ifndef TS_XCD_PIECE_LONG  // the same for chunks of 8 KB and more of the one-lane-per-board kernels
+#define TS_XCD_PIECE_LONG 32
+#endif
+#ifndef TS_XCD_PIECE_LINES  // and for the kernels that deal a board over several lanes (k_lines, k_deal)
+#define TS_XCD_PIECE_LINES 16
+#endif
 #ifndef TS_XCD_PIECE  // experiment (all launches, compile time): 0 = as the policy; P > 0 = pieces of P blocks, round-robin
 #define TS_XCD_PIECE 0
 #endif
@@ -168,8 +174,6 @@ struct KArgs {
   uint32_t bpw;         // boards per wave (k_small: 64, k_lines: 4; fewer beyond the Infinity Cache)
   uint32_t xcd_piece;   // block -> board-range mapping (xcd_contiguous_block): 0 = one contiguous eighth per XCD, P = pieces of P blocks
   uint32_t emit_edges;  // out-of-cache launches: bit 0 / 1 = first / last store instruction of a wave's chunk as write-back stores
-  uint32_t xcd_skew;    // experiment (ts_tuning): XCD x starts x * skew blocks into its range / piece (wrapping around)
-  uint32_t xcd_order;   // experiment (ts_tuning): order inside a piece: 0 ascending, 1 bit-reversed, 2 descending
   uint8_t *valid4;      // legality mask as the reference's shape: uint8 [N][4], 0 / 1 per move
 };
 
@@ -208,10 +212,10 @@ __device__ __forceinline__ f32x4 bytes_to_f4(uint32_t w) {
 // The two wait states BEHIND the store are part of it: on gfx940+ a VALU instruction must not overwrite a data
 // register of a FLAT / global store of more than 64 bits within two wait states of the store (the hardware reads the
 // last data registers that late; LLVM's hazard recognizer pads its own stores - checkVALUHazards, "12-dword store" -
-// but cannot see into an asm statement, and to the register allocator the operands are dead right behind it).  Found
+// but cannot see into an asm statement, and to the register allocator the operands are dead right behind it).
 // Any future kernel that reads its own output stream back needs a "memory" clobber on these statements.  Found
 // the hard way: an unrolled emit loop reused the data registers for the next conversion one instruction after the
-// store and the .w component of some lanes came out with the NEXT store's value (tools/check_variants_vs_oracle.py).
+// store and the .w component of some lanes came out with the NEXT store's value (tools/archive/check_variants_vs_oracle.py).
 __device__ __forceinline__ void store16_agent_scope(void *dst, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v));
 }
@@ -375,7 +379,7 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 #define TS_SMALL_BOUNDS __launch_bounds__(TS_SMALL_THREADS)
 #endif
 
-// Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only; tools/xcc_probe.py read
+// Blocks are dealt round-robin over the 8 XCDs (observed, not contractual: speed only; tools/archive/xcc_probe.py read
 // HW_REG_XCC_ID == blockIdx % 8 for every block of every launch shape used here, profiles/r02_xcc_probe.log).  This
 // bijective remap gives the blocks that share an XCD one contiguous range of boards instead of
 // every 8th block:
@@ -387,7 +391,10 @@ __device__ __forceinline__ M load_blk(const uint32_t *blk, int64_t N, int64_t n)
 //     non-coherent L2s.
 // `piece` (KArgs.xcd_piece, round 3): 0 = each XCD owns one contiguous eighth of the batch; P > 0 = pieces of P consecutive
 // blocks per XCD, dealt round-robin over the eight XCDs, so that the eight write fronts stay within 8 * P blocks of each other.
-__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks, uint32_t piece = 0, uint32_t skew = 0, uint32_t order = 0) {
+// (Round 4, on physically contiguous buffers, where an A/B is repeatable: a per-XCD skew of the start offset - XCD x starting
+// x * s blocks into its eighth / piece, s = 1 .. 11 (x 97 for eighths) - and the order of the blocks inside a piece (ascending,
+// bit-reversed, descending) change NOTHING, every cell of the grid within 0.5 %; the piece size does: profiles/r04_contig_sweep.log.)
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t nblocks, uint32_t piece = 0) {
 #if TS_XCD_REMAP
 #if TS_XCD_PIECE > 0
   piece = TS_XCD_PIECE;
@@ -396,17 +403,9 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t bid, uint32_t 
     const uint32_t full = nblocks / (8u * piece) * (8u * piece);
     if (bid >= full) return bid;
     const uint32_t xcd = bid & 7u, k = bid >> 3;
-    uint32_t i = k % piece;
-    if (skew) i = (i + xcd * skew) % piece;
-    if (order == 1 && (piece & (piece - 1)) == 0 && piece > 1) i = __brev(i) >> (__clz(piece) + 1);
-    if (order == 2) i = piece - 1 - i;
-    return ((k / piece) * 8u + xcd) * piece + i;
+    return ((k / piece) * 8u + xcd) * piece + (k % piece);
   }
   const uint32_t q = nblocks >> 3, r = nblocks & 7u, xcd = bid & 7u;
-  if (skew) {
-    const uint32_t qx = xcd < r ? q + 1 : q;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + ((bid >> 3) + xcd * skew) % qx;
-  }
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 #else
   return bid;
@@ -442,7 +441,7 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   // a.bpw boards per wave: 64 (one per lane), or fewer for launches beyond the Infinity Cache (the
   // upper lanes idle; a wave's contiguous chunk of output shrinks accordingly)
   const int bpw = (int)a.bpw;
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece, a.xcd_skew, a.xcd_order) * (blockDim.x >> 6) + wave) * bpw;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform; no block-level barrier exists in this kernel
   const int64_t N = a.N;
   const int64_t n = n0 + lane;
@@ -1043,7 +1042,7 @@ __global__ __launch_bounds__(256) void k_deal(const KArgs a) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
   const int g = lane / G, j = lane & (G - 1);
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece, a.xcd_skew, a.xcd_order) * (blockDim.x >> 6) + wave) * BPW;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece) * (blockDim.x >> 6) + wave) * BPW;
   if (n0 >= a.N) return;  // wave-uniform; no block-level barrier exists in this kernel
   const int64_t N = a.N;
   const int64_t n = n0 + g;
@@ -1314,7 +1313,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   const int wave = threadIdx.x >> 6;
   const int g = lane / G, j = lane & (G - 1);
   const int bpw = (int)a.bpw;  // boards per wave: 64 / LPB (or fewer: the upper lanes idle)
-  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece, a.xcd_skew, a.xcd_order) * (blockDim.x >> 6) + wave) * bpw;
+  const int64_t n0 = ((int64_t)xcd_contiguous_block(blockIdx.x, gridDim.x, a.xcd_piece) * (blockDim.x >> 6) + wave) * bpw;
   if (n0 >= a.N) return;  // wave-uniform
   const int64_t N = a.N;
   const int64_t n = n0 + g;
@@ -1743,47 +1742,84 @@ __global__ __launch_bounds__(256) void k_generate(uint32_t *blk, cell_t *init, c
 //   draw   : genrand_int32             (block twist of 624 words, then the tempering shifts)
 //   shuffle: for i = n-1 .. 1: j = random_interval(i); swap(x[i], x[j])            (untyped-list path)
 //   random_interval(max): mask = smallest 2^k - 1 >= max; draw 32 bits & mask until <= max
-// One thread per seed; the 624-word state and the cell list live in scratch memory (a level is
-// generated once per episode set, this is not the hot path).  Pinned by the three captures of
-// SURVEY.md §8c and by numpy itself in tests/ (numpy is importable wherever the tests run).
-__global__ __launch_bounds__(64) void k_generate_mt19937(uint32_t *blk, void *init_v, void *tgt_v, const uint32_t *seeds, int64_t N,
-                                                          int S, int T, int Tt, int K, int wide) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  constexpr int kN = 624, kM = 397;
-  uint32_t mt[kN];
-  uint16_t perm[TS_MAX_SIZE * TS_MAX_SIZE];
-  const int C = S * S, W = (C + 31) >> 5;
-  uint32_t x = seeds[n];
-  for (int i = 0; i < kN; ++i) {
-    mt[i] = x;
-    x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)(i + 1);
-  }
-  int pos = kN;
-  auto next32 = [&]() -> uint32_t {
-    if (pos == kN) {  // refill: the standard block twist
-      auto tw = [](uint32_t u, uint32_t v) -> uint32_t { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
-      int i = 0;
-      for (; i < kN - kM; ++i) mt[i] = mt[i + kM] ^ tw(mt[i], mt[i + 1]);
-      for (; i < kN - 1; ++i) mt[i] = mt[i + (kM - kN)] ^ tw(mt[i], mt[i + 1]);
-      mt[kN - 1] = mt[kM - 1] ^ tw(mt[kN - 1], mt[0]);
-      pos = 0;
+// Pinned by the three captures of SURVEY.md §8c and by numpy itself in tests/ (numpy is importable wherever the
+// tests run).  One thread per seed - the seeding recurrence is a serial chain per seed, so lanes = seeds is the
+// mapping that keeps every lane busy.  Two forms:
+//   * STREAMED (round 4; boards up to 10x10): the first 227 outputs of a freshly seeded generator need only the
+//     SEEDED words mt[k], mt[k+1] and mt[k+397] (k + 397 < 624: not yet overwritten by the twist), so the 624-word state
+//     is never materialised: one pass of the seeding chain to mt[397], then two chains advance in lock-step, three
+//     registers in all; the cell list lives in LDS (a byte per cell and lane).  A small board draws far fewer numbers
+//     than that (4x4: ~20, 8x8: ~90, 10x10: ~140 expected); a lane that runs out of window (or the whole launch, for
+//     larger boards) takes
+//   * the GENERAL form: 624-word state and cell list in scratch memory, block twist - round 3's kernel.
+constexpr int kMtN = 624, kMtM = 397;
+constexpr int kMtStreamCells = 100;           // largest board of the streamed form
+constexpr int kMtStreamWindow = kMtN - kMtM;  // 227 outputs before the first twisted word is needed
+
+__device__ __forceinline__ uint32_t mt_seed_step(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); }
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+__device__ __forceinline__ uint32_t mask_for(uint32_t i) {  // smallest 2^k - 1 >= i
+  uint32_t mask = i;
+  mask |= mask >> 1;
+  mask |= mask >> 2;
+  mask |= mask >> 4;
+  mask |= mask >> 8;
+  mask |= mask >> 16;
+  return mask;
+}
+
+// the first K + T + Tt cells of a shuffled list -> the level arrays of board n; `cell(i)` reads entry i
+template <typename F>
+__device__ __forceinline__ void mt_store_level(F cell, uint32_t *blk, void *init_v, void *tgt_v, int64_t N, int64_t n, int C, int T, int Tt, int K, int wide) {
+  const int W = (C + 31) >> 5;
+  for (int w = 0; w < W; ++w) {  // obstacle words: OR of the first K cells that fall into word w
+    uint32_t bits = 0;
+    for (int k = 0; k < K; ++k) {
+      const int c = cell(k);
+      if ((c >> 5) == w) bits |= 1u << (c & 31);
     }
-    uint32_t y = mt[pos++];
-    y ^= y >> 11;
-    y ^= (y << 7) & 0x9d2c5680u;
-    y ^= (y << 15) & 0xefc60000u;
-    y ^= y >> 18;
-    return y;
+    blk[(int64_t)w * N + n] = bits;
+  }
+  if (wide) {
+    uint16_t *init = static_cast<uint16_t *>(init_v), *tgt = static_cast<uint16_t *>(tgt_v);
+    for (int t = 0; t < T; ++t) init[(int64_t)t * N + n] = (uint16_t)cell(K + t);
+    for (int t = 0; t < Tt; ++t) tgt[(int64_t)t * N + n] = (uint16_t)cell(K + T + t);
+  } else {
+    uint8_t *init = static_cast<uint8_t *>(init_v), *tgt = static_cast<uint8_t *>(tgt_v);
+    for (int t = 0; t < T; ++t) init[(int64_t)t * N + n] = (uint8_t)cell(K + t);
+    for (int t = 0; t < Tt; ++t) tgt[(int64_t)t * N + n] = (uint8_t)cell(K + T + t);
+  }
+}
+
+__device__ __noinline__ void mt_level_general(uint32_t seed, uint32_t *blk, void *init_v, void *tgt_v, int64_t N, int64_t n, int C, int T, int Tt, int K, int wide) {
+  uint32_t mt[kMtN];
+  uint16_t perm[TS_MAX_SIZE * TS_MAX_SIZE];
+  uint32_t x = seed;
+  for (int i = 0; i < kMtN; ++i) {
+    mt[i] = x;
+    x = mt_seed_step(x, (uint32_t)(i + 1));
+  }
+  // The block twist, one word at a time and only as far as outputs are drawn: word i of the twisted state depends on words i,
+  // i + 1 and i + 397 (mod 624) as they stand when a sequential block twist reaches i - old above i, new below - which is
+  // exactly their content here (a 15x15 board draws ~300 of the first 624 outputs: half a twist saved).
+  int pos = 0;
+  auto next32 = [&]() -> uint32_t {
+    const int i = pos, i1 = i + 1 == kMtN ? 0 : i + 1, im = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;
+    const uint32_t y = mt[im] ^ mt_twist(mt[i], mt[i1]);
+    mt[i] = y;
+    pos = i1;
+    return mt_temper(y);
   };
   for (int i = 0; i < C; ++i) perm[i] = (uint16_t)i;
   for (int i = C - 1; i >= 1; --i) {
-    uint32_t mask = (uint32_t)i;
-    mask |= mask >> 1;
-    mask |= mask >> 2;
-    mask |= mask >> 4;
-    mask |= mask >> 8;
-    mask |= mask >> 16;
+    const uint32_t mask = mask_for((uint32_t)i);
     uint32_t j;
     do {
       j = next32() & mask;
@@ -1792,21 +1828,50 @@ __global__ __launch_bounds__(64) void k_generate_mt19937(uint32_t *blk, void *in
     perm[i] = perm[j];
     perm[j] = a;
   }
-  for (int w = 0; w < W; ++w) {  // obstacle words: OR of the first K cells that fall into word w
-    uint32_t bits = 0;
-    for (int k = 0; k < K; ++k)
-      if ((perm[k] >> 5) == w) bits |= 1u << (perm[k] & 31);
-    blk[(int64_t)w * N + n] = bits;
+  mt_store_level([&](int i) -> int { return perm[i]; }, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
+}
+
+__global__ __launch_bounds__(64) void k_generate_mt19937(uint32_t *blk, void *init_v, void *tgt_v, const uint32_t *seeds, int64_t N,
+                                                          int S, int T, int Tt, int K, int wide, int window) {
+  __shared__ unsigned char cells[kMtStreamCells * kWave];  // streamed form: the cell list, [cell][lane]
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int C = S * S;
+  const uint32_t seed = seeds[n];
+  if (C <= kMtStreamCells && window > 0) {  // uniform
+    const int lane = threadIdx.x;
+    uint32_t a0 = seed, a1 = mt_seed_step(seed, 1u);  // mt[k], mt[k + 1]
+    uint32_t b = a1;
+    for (uint32_t i = 2; i <= (uint32_t)kMtM; ++i) b = mt_seed_step(b, i);  // mt[k + 397]
+    int k = 0;
+    bool in_window = true;
+    for (int i = 0; i < C; ++i) cells[i * kWave + lane] = (unsigned char)i;
+    for (int i = C - 1; i >= 1 && in_window; --i) {
+      const uint32_t mask = mask_for((uint32_t)i);
+      uint32_t j;
+      do {
+        if (k >= window) {
+          in_window = false;
+          break;
+        }
+        j = mt_temper(b ^ mt_twist(a0, a1)) & mask;  // output k of the generator
+        a0 = a1;
+        a1 = mt_seed_step(a1, (uint32_t)(k + 2));
+        b = mt_seed_step(b, (uint32_t)(k + kMtM + 1));
+        ++k;
+      } while (j > (uint32_t)i);
+      if (in_window) {
+        const unsigned char t = cells[i * kWave + lane];
+        cells[i * kWave + lane] = cells[j * kWave + lane];
+        cells[j * kWave + lane] = t;
+      }
+    }
+    if (in_window) {
+      mt_store_level([&](int i) -> int { return cells[i * kWave + lane]; }, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
+      return;
+    }
   }
-  if (wide) {
-    uint16_t *init = static_cast<uint16_t *>(init_v), *tgt = static_cast<uint16_t *>(tgt_v);
-    for (int t = 0; t < T; ++t) init[(int64_t)t * N + n] = perm[K + t];
-    for (int t = 0; t < Tt; ++t) tgt[(int64_t)t * N + n] = perm[K + T + t];
-  } else {
-    uint8_t *init = static_cast<uint8_t *>(init_v), *tgt = static_cast<uint8_t *>(tgt_v);
-    for (int t = 0; t < T; ++t) init[(int64_t)t * N + n] = (uint8_t)perm[K + t];
-    for (int t = 0; t < Tt; ++t) tgt[(int64_t)t * N + n] = (uint8_t)perm[K + T + t];
-  }
+  mt_level_general(seed, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
 }
 
 // uint8 -> float32, 16 output bytes per lane, one KiB per wave, workgroups in address order: the
@@ -1834,8 +1899,8 @@ std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_T
 std::atomic<int64_t> g_lines_lanes{0};  // ts_tuning(TS_TUNE_LINES_LANES): 0 = by tile count, 4 / 8 / 16 = forced where instantiated
 std::atomic<int64_t> g_lines_bpw{0};    // ts_tuning(TS_TUNE_LINES_BPW): 0 = policy, else boards per wave of k_lines (the other lanes idle)
 std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): INT64_MAX = policy, 0 = eighths, P = pieces of P blocks (out-of-cache launches)
+std::atomic<int64_t> g_mt_window{kMtStreamWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
 std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
-std::atomic<int64_t> g_xcd_skew{0}, g_xcd_order{0};  // ts_tuning(TS_TUNE_XCD_SKEW / TS_TUNE_XCD_ORDER): experiments (round 4)
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
 std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
 
@@ -1966,7 +2031,7 @@ inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
 
 // Dynamic LDS a block may ask for.  64 KiB keeps at least two blocks on a CU (160 KiB of LDS);
 // blocks shrink to 2 or 1 wave(s) when four carves would not fit, and no wave of any kernel here
-// needs more than ~36 KiB.  The hardware limit is higher: tools/lds_probe.py ran self-checking
+// needs more than ~36 KiB.  The hardware limit is higher: tools/archive/lds_probe.py ran self-checking
 // launches at every size up to hipDeviceAttributeMaxSharedMemoryPerBlock = 163,840 B without
 // hipFuncSetAttribute and without a single foreign write (profiles/r02_lds_probe.log).
 // Round 1 capped this at 60 KiB, blaming a corruption seen on 8x8 / 20 tiles on requests of exactly 65,536 B.  That was
@@ -2048,15 +2113,24 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
 // wave has six store instructions: 115 -> 194 us with two of them write-back).  profiles/r03_emit_edges_ab.log
 uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= 8u * 1024u ? 3u : 0u; }
 
-// Block -> board-range mapping of out-of-cache launches (KArgs.xcd_piece, xcd_contiguous_block).  One contiguous eighth of
-// the batch per XCD is the best mapping on a "fast" allocation of the output buffers and among the worst on a "slow" one (the
-// 4x4 launch at 4M boards: 116.7 us fast, 129 slow); pieces of 64 one-wave blocks per XCD, dealt round-robin, keep the eight
-// write fronts within a few MB of each other and gave 121.5 us on every allocation of that launch - and 118 against 137-140 on
-// another box (profiles/r03_xcd_piece_ab.log).  For longer chunks the picture changes from box to box (cfg2 with pieces of 64:
-// 133 -> 125 us on one box, 132 -> 139 on the next, where 32 gave 124; 7x7 / 20x20 and up lose 15-25 % with 64 on that box), so
-// the static policy uses pieces only for short chunks and the per-environment rating (VecTilerSliderEnv placement_trials)
-// tries 32 / 64 / 128 / eighths on the buffers it has.
-uint32_t piece_policy(uint64_t chunk) { return chunk < 8u * 1024u ? TS_XCD_PIECE_POLICY : 0u; }
+// Block -> board-range mapping of out-of-cache launches (KArgs.xcd_piece, xcd_contiguous_block).
+// Round 3 (ordinary allocations, where the same launch runs at one of two speeds depending on the physical pages behind the
+// output buffers): one contiguous eighth of the batch per XCD is the best mapping on a "fast" allocation and among the worst on
+// a "slow" one; pieces of P one-wave blocks per XCD, dealt round-robin, keep the eight write fronts within 8 P chunks of each
+// other and are the same on every allocation (profiles/r03_xcd_piece_ab.log).
+// Round 4: the policy is set on PHYSICALLY CONTIGUOUS output buffers (hipExtMallocWithFlags(hipDeviceMallocContiguous), the
+// host's default beyond 256 MiB): the same physical layout in every process, so the A/B is an experiment, not a lottery
+// (profiles/r04_contig_sweep.log, r04_piece_by_shape.log; us per step, eighths -> best piece): cfg2 122.2 -> 118.4 (pieces of 32),
+// cfg4 113.9 -> 107.7 (16), 4x4 at 4M boards 133 -> 124.5 (64).  Too small a piece loses (cfg2 with 8: 120.7), too large a one
+// approaches eighths again.
+uint32_t piece_policy(bool lines_kernel, uint64_t chunk) {
+#if TS_XCD_PIECE_POLICY >= 0
+  if (lines_kernel) return TS_XCD_PIECE_LINES;
+  return chunk < 8u * 1024u ? TS_XCD_PIECE_POLICY : TS_XCD_PIECE_LONG;
+#else
+  return 0u;
+#endif
+}
 
 // Boards per wave of k_small.  Beyond the Infinity Cache the register-path kernels run HALF waves —
 // 32 boards, the upper lanes idle — once a full wave would write 8 KB or more: the transition
@@ -2124,8 +2198,6 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                   : piece <= 0x7fffffff ? (uint32_t)piece : 0xffffffffu;  // 0xffffffff: by kernel, below
     const int64_t forced = g_emit_edges.load(std::memory_order_relaxed);
     a.emit_edges = d->emit_edges > 0 ? (uint32_t)(d->emit_edges - 1) : forced >= 0 && forced <= 3 ? (uint32_t)forced : 0xffu;  // 0xff: by shape, below
-    a.xcd_skew = (uint32_t)g_xcd_skew.load(std::memory_order_relaxed);
-    a.xcd_order = (uint32_t)g_xcd_order.load(std::memory_order_relaxed);
   }
   hipStream_t hs = (hipStream_t)stream;
 
@@ -2171,7 +2243,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
         Residency res = ooc_residency(a.nt != 0, true, false, (uint64_t)bpw * out_pb, T);
         apply_launch_hint(res, d->launch_hint);
         if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
-        if (a.xcd_piece == 0xffffffffu) a.xcd_piece = 0u;
+        if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
         int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
         while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
         const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
@@ -2192,7 +2264,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                                             (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7));
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
-    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy((uint64_t)a.bpw * out_per_board);
+    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(false, (uint64_t)a.bpw * out_per_board);
     apply_launch_hint(res, d->launch_hint);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
@@ -2245,7 +2317,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                                         (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)), T);
     apply_launch_hint(res, d->launch_hint);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
-    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = 0u;  // k_lines: see piece_policy
+    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
@@ -2460,10 +2532,10 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_LINES_BPW ? &g_lines_bpw
                                : key == TS_TUNE_EMIT_EDGES ? &g_emit_edges
                                : key == TS_TUNE_XCD_PIECE ? &g_xcd_piece
-                               : key == TS_TUNE_XCD_SKEW ? &g_xcd_skew
-                               : key == TS_TUNE_XCD_ORDER ? &g_xcd_order
-                               : key == TS_TUNE_DEAL ? &g_deal_enabled : nullptr;
+                               : key == TS_TUNE_DEAL ? &g_deal_enabled
+                               : key == TS_TUNE_MT_WINDOW ? &g_mt_window : nullptr;
   if (!knob) return -1;
+  if (key == TS_TUNE_MT_WINDOW && value > kMtStreamWindow) value = kMtStreamWindow;  // beyond it the twisted words are needed
   return value >= 0 ? knob->exchange(value) : knob->load();
 }
 
@@ -2518,7 +2590,7 @@ int32_t ts_generate_mt19937(const ts_dims *dims, const ts_state *st, const uint3
   if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
   hipLaunchKernelGGL(k_generate_mt19937, dim3((uint32_t)blocks), dim3(64), 0, (hipStream_t)stream, (uint32_t *)st->blk,
                      const_cast<void *>(st->init), const_cast<void *>(st->tgt), seeds, dims->n_boards, dims->size, dims->n_tiles,
-                     dims->n_targets, n_obstacles, dims->size > 16 ? 1 : 0);
+                     dims->n_targets, n_obstacles, dims->size > 16 ? 1 : 0, (int)g_mt_window.load(std::memory_order_relaxed));
   return finish_launch();
 }
 

@@ -26,7 +26,11 @@ What the collective reads while the next step runs (the buffers that are double-
   * cell ids (compact form): `pos` is single-buffered state that step k+1 rewrites in place, so
     every gather first SNAPSHOTS it, stream-ordered behind step k, into one of two send slots
     (T bytes per board: 2 MiB at 1M 4x4 boards) and the collective reads the slot.
-Wait for gather k before issuing gather k+2 (its send slot / observation buffer is reused then).
+The RECEIVE side (obs_all and the padded / byte / cell-id images it is assembled from) is single-buffered, and all three
+forms assemble into the same observation image: ONE gather in flight per gatherer.  Wait for gather k before issuing gather
+k+1 - issuing a second one while a handle is unfinished raises RuntimeError instead of letting collective k+1 overwrite what
+handle k is about to finish from.  (The send side's two slots exist because gather k may still be READING its slot on the
+backend's stream when step k+1 - and the snapshot / padded copy of gather k+1 - are enqueued on the caller's.)
 
 Shards may differ in size (shard_bounds hands out sizes that differ by at most one board):
 all-gather needs equal pieces, so every rank then sends max-shard-size boards (padded) and the
@@ -81,6 +85,10 @@ class GatherHandle:
     def __init__(self, work, finish):
         self._work, self._finish, self._result = work, finish, None
 
+    @property
+    def finished(self):
+        return self._finish is None
+
     def wait(self):
         if self._finish is not None:
             for w in self._work:
@@ -122,6 +130,7 @@ class ObservationGatherer:
         self._recv_u8 = (torch.empty((W, nm) + obs_shape, dtype=torch.uint8, device=dev)
                          if env._obs.dtype == torch.uint8 else None)
         self._send_pad = {}  # padded copies of this rank's buffers (only on ranks with n < nmax)
+        self._pending = None  # the one gather that may be in flight (the receive side is single-buffered)
         # compact state: dtypes come from the environment (uint8 cell ids up to 16x16, int16 above)
         T = env._pos.shape[0]
         self._pos_send = [torch.zeros((T, nm), dtype=env._pos.dtype, device=dev) for _ in range(2)]  # snapshots
@@ -190,7 +199,14 @@ class ObservationGatherer:
 
     def _finish(self, work, fn, async_op):
         h = GatherHandle(work, fn)
+        self._pending = h
         return h if async_op else h.wait()
+
+    def _require_idle(self):
+        """Called before a gather touches any buffer: the previous handle must have been waited for."""
+        if self._pending is not None and not self._pending.finished:
+            raise RuntimeError("a gather is still in flight on this ObservationGatherer: call wait() on its handle before "
+                               "issuing the next one (the receive buffers are single-buffered)")
 
     def _check_async_obs(self, async_op):
         ring = getattr(self.env, "_obs_ring", None)
@@ -206,6 +222,7 @@ class ObservationGatherer:
         if obs.dtype != torch.float32:
             raise ValueError("gather_observations needs a float32 environment; use gather_u8_and_expand")
         self._check_async_obs(async_op)
+        self._require_idle()
         w = self._gather(self._padded_obs, self._padded_rows(obs, "obs"), async_op)
         return self._finish([w], self._compact, async_op)
 
@@ -214,6 +231,7 @@ class ObservationGatherer:
             raise ValueError('gather_u8_and_expand needs an environment built with obs_dtype="uint8"')
         obs = self.env._obs if obs is None else obs
         self._check_async_obs(async_op)
+        self._require_idle()
         w = self._gather(self._recv_u8, self._padded_rows(obs, "obs_u8"), async_op)
 
         def fin():  # ONE launch over everything received (padding boards included), then drop the padding
@@ -223,6 +241,7 @@ class ObservationGatherer:
 
     def gather_compact_and_encode(self, async_op=False):
         env = self.env
+        self._require_idle()
         w = None
         if env._pos.numel():
             # snapshot, stream-ordered behind the step that produced these cells: the collective (on the
