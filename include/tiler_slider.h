@@ -102,17 +102,21 @@ typedef struct ts_dims {
   int32_t max_steps;   /* >= 1                       (TilerSliderEnv.max_steps) */
   /* Launch policy of THIS call (speed only, never results; 0 everywhere = the library's own policy).  They matter for
    * launches whose outputs do not fit the 256 MiB Infinity Cache, where the best values depend on the shape and on where
-   * the output buffers were allocated; VecTilerSliderEnv rates a few combinations at construction. */
+   * the output buffers were allocated.  The library's policy assumes physically contiguous output
+   * buffers; VecTilerSliderEnv(placement_trials >= 1) rates a few combinations at construction for other memory. */
   int32_t launch_hint; /* -8 .. +8: resident blocks per CU relative to the policy.  Anything else: TS_ERR_DIMS.
                         * (The field was `reserved`, must-be-zero, before ABI v3.) */
   int32_t emit_edges;  /* ABI v4.  0 = policy; 1 + e (e = 0 .. 3): bit 0 / bit 1 of e = the first / last store instruction
                         * of every wave's chunk of observation is a write-back store instead of a nontemporal one. */
-  int32_t lines_lanes; /* ABI v4.  0 = policy; 4 / 8 / 16 = lanes per board of the kernel for boards above 8x8, where
-                        * that form exists for the shape (else the policy's choice is taken). */
+  int32_t lines_lanes; /* ABI v4.  0 = policy; 4 / 8 / 16 = lanes per board of the kernels that deal a board over several
+                        * lanes (boards above 8x8; 7x7 / 8x8 with more than 8 tiles: 4 / 8), where that form exists for the
+                        * shape (else the policy's choice is taken). */
   int32_t xcd_piece;   /* ABI v4.  0 = policy; 1 = the blocks that share an XCD get one contiguous eighth of the batch;
-                        * P >= 2 = pieces of P consecutive blocks per XCD, dealt round-robin over the eight XCDs (the
-                        * eight write fronts then stay close together: a few % slower than eighths on a "fast" allocation
-                        * of the output buffers, up to 6 % faster on a "slow" one). */
+                        * P >= 2 = pieces of P consecutive blocks per XCD, dealt round-robin over the eight XCDs (the eight
+                        * write fronts then stay close together).  The policy - pieces of 16 / 32 / 64 by kernel and chunk -
+                        * is tuned on physically contiguous output buffers (hipExtMallocWithFlags(hipDeviceMallocContiguous),
+                        * what the shipped host code allocates beyond 256 MiB): cfg2 122 -> 118 us, cfg4 114 -> 107 against
+                        * eighths.  On ordinary allocations eighths win on some ("fast") buffers and lose on others. */
 } ts_dims;
 
 typedef struct ts_state {
@@ -264,13 +268,15 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
 #define TS_TUNE_LINES_BPW 3
 #define TS_TUNE_EMIT_EDGES 4
 #define TS_TUNE_XCD_PIECE 5
-#define TS_TUNE_DEAL 6      /* 1 (default): boards up to 8x8 with 9 .. 64 tiles run with a board's tiles dealt over 4 or 8 lanes
-                             * (k_deal; TS_TUNE_LINES_LANES / ts_dims.lines_lanes = 4 or 8 choose for 9 .. 16 tiles); 0: one lane
-                             * per board as for any other tile count (k_small), kept for A/B and as the parity cross-check */
-#define TS_TUNE_MT_WINDOW 7 /* ts_generate_mt19937 on boards up to 10x10 streams the generator's first outputs from the seeding
-                             * recurrence without building its 624-word state; a seed that needs more than `value` outputs
-                             * (default and maximum 227) takes the general form.  0 = always the general form.  Results never
-                             * differ; tests shrink the window to exercise the hand-over. */
+#define TS_TUNE_DEAL 6      /* 1 (default): 7x7 and 8x8 boards with 9 .. 64 tiles run with a board's tiles dealt over 4 lanes (up to
+                             * 32 tiles) or 8 (k_deal; TS_TUNE_LINES_LANES / ts_dims.lines_lanes = 4 or 8 force a form where it
+                             * exists); 0: one lane per board as for any other tile count (k_small), kept for A/B and as the
+                             * parity cross-check */
+#define TS_TUNE_MT_WINDOW 7 /* ts_generate_mt19937 on boards up to 18x18 streams the generator's outputs from the seeding recurrence
+                             * (plus, beyond output 227, a delay line of earlier outputs) without building its 624-word state; a
+                             * seed that needs more than `value` outputs (default and maximum 623; boards up to 10x10: at most 227)
+                             * takes the general form.  0 = always the general form.  Results never differ; tests shrink the
+                             * window to exercise the hand-over. */
 int64_t ts_tuning(int32_t key, int64_t value);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */

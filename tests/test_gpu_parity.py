@@ -453,7 +453,11 @@ LARGE_BATCH_SHAPES = [
 def test_large_batches_vs_oracle(torch_cuda, oracle, S, T, K, mc, N):
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv
-    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=4242 + S)
+    if K + 2 * T <= S * S:
+        blk, init, tgt = oracle.generate(S, T, T, K, N, seed=4242 + S)
+    else:  # dense boards: targets drawn on their own (they may then sit under tiles or obstacles)
+        blk, init, _ = oracle.generate(S, T, 0, K, N, seed=4242 + S)
+        _, _, tgt = oracle.generate(S, 0, T, 0, N, seed=5242 + S)
     ref = oracle.OracleBatch(S, mc, 2**30, blk, init, tgt)
     env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=2**30, auto_reset=True,
                                         with_reward=True, with_valid_moves=True)
@@ -522,16 +526,20 @@ def test_lines_kernel_lanes_per_board_forced(torch_cuda, oracle, lanes, S, T, Tt
         L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, nt_before)
 
 
-@pytest.mark.parametrize("form", ["policy", "lanes8", "one_lane"])
+@pytest.mark.parametrize("form", ["policy", "lanes4", "lanes8", "one_lane"])
 @pytest.mark.parametrize("S,T,Tt,K,mc,N", [(4, 10, 10, 2, True, 1031), (4, 16, 16, 0, False, 130), (5, 12, 12, 4, False, 517), (5, 20, 20, 3, True, 777),
                                            (5, 25, 25, 0, True, 67), (6, 9, 9, 6, True, 640), (6, 17, 17, 5, False, 333), (6, 33, 33, 1, True, 200),
                                            (7, 12, 12, 9, True, 321), (7, 40, 40, 3, False, 259), (8, 9, 9, 8, False, 1500), (8, 16, 16, 10, True, 900),
                                            (8, 17, 17, 10, True, 513), (8, 20, 20, 10, True, 4099), (8, 32, 32, 10, False, 258), (8, 33, 33, 5, True, 131),
                                            (8, 64, 64, 0, False, 66), (6, 10, 12, 4, True, 300), (8, 12, 9, 8, False, 301), (8, 3, 20, 9, True, 302),
-                                           (7, 20, 2, 6, False, 303), (5, 0, 12, 3, False, 65), (8, 30, 64, 4, True, 129)])
+                                           (7, 20, 2, 6, False, 303), (5, 0, 12, 3, False, 65), (8, 30, 64, 4, True, 129),
+                                           # every tiles-per-lane form of 4 and of 8 lanes (3 .. 8 / 2 .. 8)
+                                           (8, 24, 24, 6, True, 260), (8, 28, 28, 4, False, 261), (8, 41, 41, 3, True, 132), (8, 50, 50, 2, False, 133),
+                                           (7, 24, 24, 5, False, 262), (7, 28, 28, 3, True, 263), (7, 32, 32, 2, False, 264), (7, 45, 45, 1, True, 134),
+                                           (7, 49, 49, 0, False, 70)])
 def test_dealt_tiles_kernel_forms(torch_cuda, oracle, form, S, T, Tt, K, mc, N):
     """Boards up to 8x8 with 9 .. 64 tiles / targets: k_deal deals a board's tiles over 4 or 8 lanes (round 4).  Every form
-    (the policy's; 8 lanes forced for 9 .. 16 tiles; the old one-lane-per-board path, TS_TUNE_DEAL = 0) must give the oracle's
+    (the policy's; 4 / 8 lanes forced where that form exists; the old one-lane-per-board path, TS_TUNE_DEAL = 0) must give the oracle's
     outputs - optional outputs, uint8 observation, duplicate targets, unequal counts, cache-resident and out-of-cache kernels."""
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv, _cabi
@@ -544,7 +552,7 @@ def test_dealt_tiles_kernel_forms(torch_cuda, oracle, form, S, T, Tt, K, mc, N):
         tgt[1, 3::11] = tgt[0, 3::11]  # duplicate targets: the "highest index wins" fix-up
     if T == Tt and T:
         tgt[:, ::7] = init[:, ::7]      # some boards solved at the start
-    lanes_before = L.ts_tuning(_cabi.TUNE_LINES_LANES, 8 if form == "lanes8" else 0)
+    lanes_before = L.ts_tuning(_cabi.TUNE_LINES_LANES, {"lanes8": 8, "lanes4": 4}.get(form, 0))
     deal_before = L.ts_tuning(_cabi.TUNE_DEAL, 0 if form == "one_lane" else 1)
     nt_before = L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, -1)
     try:

@@ -104,19 +104,20 @@ def test_hip_generator_survey_captures_and_scale():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("window", [0, 3, 24, 90, 227])
+@pytest.mark.parametrize("window", [0, 3, 24, 90, 227, 228, 300, 400, 623])
 def test_streamed_generator_hands_over_to_the_general_form(oracle, window):
-    """Boards up to 10x10 stream the generator's first outputs from the seeding recurrence (no 624-word state); a seed that
-    needs more outputs than the window takes the general form.  With shrunken windows some / most / all seeds of a batch
-    hand over - the levels must not change (TS_TUNE_MT_WINDOW)."""
+    """Boards up to 18x18 stream the generator's outputs from the seeding recurrence (no 624-word state; beyond output 227 a
+    delay line of earlier outputs); a seed that needs more outputs than the window takes the general form.  With shrunken
+    windows some / most / all seeds of a batch hand over - the levels must not change (TS_TUNE_MT_WINDOW)."""
     import torch
     from tiler_slider_amd import TilerSliderEnvFactory, _cabi
     L = _cabi.lib()
     before = L.ts_tuning(_cabi.TUNE_MT_WINDOW, window)
     try:
-        assert before == 227 and L.ts_tuning(_cabi.TUNE_MT_WINDOW, -1) == window
-        for index, (size, T, K) in enumerate([(2, 1, 1), (4, 2, 2), (5, 2, 3), (8, 20, 10), (10, 5, 5), (10, 40, 20)]):
-            seeds = seeds_for(50 + index, 3000)
+        assert before == 623 and L.ts_tuning(_cabi.TUNE_MT_WINDOW, -1) == window
+        for index, (size, T, K) in enumerate([(2, 1, 1), (4, 2, 2), (5, 2, 3), (8, 20, 10), (10, 5, 5), (10, 40, 20), (11, 6, 8), (12, 8, 16),
+                                              (15, 32, 24), (16, 100, 50), (17, 3, 20), (18, 30, 40), (19, 5, 5)]):
+            seeds = seeds_for(50 + index, 3000 if size <= 10 else 700)
             env = TilerSliderEnvFactory.create_vec_env_from_seeds(seeds, size=size, num_tiles=T, num_obstacles=K)
             blk, init, tgt = oracle.generate_mt19937(size, T, T, K, seeds)
             np.testing.assert_array_equal(env._blk.cpu().numpy().view(np.uint32), blk)
@@ -124,4 +125,4 @@ def test_streamed_generator_hands_over_to_the_general_form(oracle, window):
             np.testing.assert_array_equal(env._tgt.cpu().numpy().astype(np.int64), tgt.astype(np.int64))
     finally:
         L.ts_tuning(_cabi.TUNE_MT_WINDOW, before)
-    assert L.ts_tuning(_cabi.TUNE_MT_WINDOW, 1000) == 227 and L.ts_tuning(_cabi.TUNE_MT_WINDOW, -1) == 227  # clamped
+    assert L.ts_tuning(_cabi.TUNE_MT_WINDOW, 1000) == 623 and L.ts_tuning(_cabi.TUNE_MT_WINDOW, -1) == 623  # clamped

@@ -104,8 +104,8 @@
 #ifndef TS_WAVES_PER_BLOCK
 #define TS_WAVES_PER_BLOCK 4
 #endif
-#ifndef TS_DEAL_LANES_SMALL  // lanes per board of k_deal for 9 .. 16 tiles (4 or 8)
-#define TS_DEAL_LANES_SMALL 4
+#ifndef TS_DEAL_LANES4_MAX  // k_deal: up to this many tiles a board is dealt over 4 lanes, above over 8
+#define TS_DEAL_LANES4_MAX 32
 #endif
 #ifndef TS_LINES_LDS_PAD  // diagnostic: extra dynamic LDS per wave of k_lines (lowers the resident waves)
 #define TS_LINES_LDS_PAD 0
@@ -751,7 +751,12 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < nbc ? (nb - c0) : nbc;
-      emit_bytes_as_f32<NT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
+      // a wave's first chunk starts on a 128-byte line (n0 is a multiple of 32 boards); later chunks do so only when
+      // 4 * D * nbc is a multiple of 128 - not for odd board sizes in multi-colour mode with fewer than 32 boards per chunk
+      if (((nbc * D) & 31) == 0)
+        emit_bytes_as_f32<NT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
+      else
+        emit_bytes_as_f32<NT, true>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
     }
   } else if (EXTRAS && a.onehot) {
     // Fallback for very many planes (one board's image above the LDS budget): every output
@@ -1019,8 +1024,12 @@ __global__ __launch_bounds__(256) void k_multi(const KArgs a) {
 //   * duplicate target cells ("highest index wins", state.py:209-211) show as popcount(target mask) != n_targets and
 //     are fixed up as in k_lines;
 //   * one-hot planes: the wave's boards as one stream cut into 8 KiB pieces, as in k_lines.
-// Host policy (launch()): 9 .. 16 tiles G = 4 / TPL = 4 (or G = 8 / TPL = 2), up to 32 G = 8 / TPL = 4, up to 64 G = 8 / TPL = 8;
-// anything else (n_targets > 64: repeated targets) stays with k_small's any-tile-count path.
+// Host policy (launch()): 7x7 and 8x8 only; 9 .. 32 tiles over 4 lanes, 33 .. 64 over 8, TPL = ceil(tiles / lanes) exactly;
+// full occupancy (no bound on resident blocks).  us per step of a 500 MB batch, one lane per board -> dealt
+// (profiles/r04_deal_ab.log): 8x8 with 9 tiles 86.5 -> 72.6 (0.77 -> 0.91 of the HBM roofline), 12 tiles 87.5 -> 74.0 (0.91),
+// 16: 91.9 -> 78.2, 20: 96.4 -> 85.7 (0.72 -> 0.81), 28: 101.7 -> 94.0; 7x7 with 12: 88.9 -> 81.8.  Anything else (smaller
+// boards: their observation is too short for a 16-board wave to pay for the group shuffles; n_targets > 64: repeated
+// targets) stays with k_small's any-tile-count path.
 // ------------------------------------------------------------------------------------------
 template <int G, typename M>
 __device__ __forceinline__ M group_or(M v) {
@@ -1744,17 +1753,20 @@ __global__ __launch_bounds__(256) void k_generate(uint32_t *blk, cell_t *init, c
 //   random_interval(max): mask = smallest 2^k - 1 >= max; draw 32 bits & mask until <= max
 // Pinned by the three captures of SURVEY.md §8c and by numpy itself in tests/ (numpy is importable wherever the
 // tests run).  One thread per seed - the seeding recurrence is a serial chain per seed, so lanes = seeds is the
-// mapping that keeps every lane busy.  Two forms:
-//   * STREAMED (round 4; boards up to 10x10): the first 227 outputs of a freshly seeded generator need only the
-//     SEEDED words mt[k], mt[k+1] and mt[k+397] (k + 397 < 624: not yet overwritten by the twist), so the 624-word state
-//     is never materialised: one pass of the seeding chain to mt[397], then two chains advance in lock-step, three
-//     registers in all; the cell list lives in LDS (a byte per cell and lane).  A small board draws far fewer numbers
-//     than that (4x4: ~20, 8x8: ~90, 10x10: ~140 expected); a lane that runs out of window (or the whole launch, for
-//     larger boards) takes
-//   * the GENERAL form: 624-word state and cell list in scratch memory, block twist - round 3's kernel.
+// mapping that keeps every lane busy.  Forms:
+//   * STREAMED (round 4; boards up to 18x18): the first outputs of a freshly seeded generator need only the SEEDED words
+//     mt[k], mt[k+1] and - while k + 397 < 624, i.e. for the first 227 outputs - mt[k+397]: one pass of the seeding chain
+//     to mt[397], then two chains advance in lock-step, three registers in all, and the 624-word state is never built.
+//     Boards up to 10x10 (4x4 draws ~20 numbers, 8x8 ~90, 10x10 ~140) stop there; up to 18x18 (15x15: ~330, 18x18: ~470
+//     of at most 623) a delay line of earlier outputs supplies the twisted words beyond (k_generate_mt19937_stream).
+//     The cell list lives in LDS.  A seed that runs out of window takes
+//   * the GENERAL form: 624-word state and cell list in scratch memory, block twist - round 3's kernel; also every
+//     board above 18x18 (32x32 draws ~1,400 numbers: more than two block twists).
 constexpr int kMtN = 624, kMtM = 397;
-constexpr int kMtStreamCells = 100;           // largest board of the streamed form
+constexpr int kMtStreamCells = 100;           // largest board of the short streamed form
 constexpr int kMtStreamWindow = kMtN - kMtM;  // 227 outputs before the first twisted word is needed
+constexpr int kMtLongCells = 324;             // largest board of the streamed form with the delay line (18x18)
+constexpr int kMtLongWindow = kMtN - 1;       // output 623 needs twisted word 0 in place of a seeded one: not streamed
 
 __device__ __forceinline__ uint32_t mt_seed_step(uint32_t x, uint32_t i) { return 1812433253u * (x ^ (x >> 30)) + i; }
 __device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); }
@@ -1806,16 +1818,19 @@ __device__ __noinline__ void mt_level_general(uint32_t seed, uint32_t *blk, void
     mt[i] = x;
     x = mt_seed_step(x, (uint32_t)(i + 1));
   }
-  // The block twist, one word at a time and only as far as outputs are drawn: word i of the twisted state depends on words i,
-  // i + 1 and i + 397 (mod 624) as they stand when a sequential block twist reaches i - old above i, new below - which is
-  // exactly their content here (a 15x15 board draws ~300 of the first 624 outputs: half a twist saved).
-  int pos = 0;
+  // (Round 4 tried the twist one word at a time, only as far as outputs are drawn: the per-lane index - lanes drift apart
+  // with every rejected draw - makes each scratch access 64 separate transactions: 15x15 2.5 -> 4.3 ms.  The block twist walks
+  // the state at a uniform index: 256 contiguous bytes per wave and access.)
+  int pos = kMtN;
   auto next32 = [&]() -> uint32_t {
-    const int i = pos, i1 = i + 1 == kMtN ? 0 : i + 1, im = i + kMtM >= kMtN ? i + kMtM - kMtN : i + kMtM;
-    const uint32_t y = mt[im] ^ mt_twist(mt[i], mt[i1]);
-    mt[i] = y;
-    pos = i1;
-    return mt_temper(y);
+    if (pos == kMtN) {  // refill: the standard block twist
+      int i = 0;
+      for (; i < kMtN - kMtM; ++i) mt[i] = mt[i + kMtM] ^ mt_twist(mt[i], mt[i + 1]);
+      for (; i < kMtN - 1; ++i) mt[i] = mt[i + (kMtM - kMtN)] ^ mt_twist(mt[i], mt[i + 1]);
+      mt[kMtN - 1] = mt[kMtM - 1] ^ mt_twist(mt[kMtN - 1], mt[0]);
+      pos = 0;
+    }
+    return mt_temper(mt[pos++]);
   };
   for (int i = 0; i < C; ++i) perm[i] = (uint16_t)i;
   for (int i = C - 1; i >= 1; --i) {
@@ -1831,47 +1846,65 @@ __device__ __noinline__ void mt_level_general(uint32_t seed, uint32_t *blk, void
   mt_store_level([&](int i) -> int { return perm[i]; }, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
 }
 
-__global__ __launch_bounds__(64) void k_generate_mt19937(uint32_t *blk, void *init_v, void *tgt_v, const uint32_t *seeds, int64_t N,
-                                                          int S, int T, int Tt, int K, int wide, int window) {
-  __shared__ unsigned char cells[kMtStreamCells * kWave];  // streamed form: the cell list, [cell][lane]
+__global__ __launch_bounds__(64) void k_generate_mt19937_general(uint32_t *blk, void *init_v, void *tgt_v, const uint32_t *seeds, int64_t N,
+                                                                  int S, int T, int Tt, int K, int wide) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  if (n < N) mt_level_general(seeds[n], blk, init_v, tgt_v, N, n, S * S, T, Tt, K, wide);
+}
+
+// The streamed forms.  All 64 seeds of a wave draw output k of their generators in the same iteration (a lane whose draw is
+// rejected by random_interval just does not advance its shuffle), so k - and with it every index into the delay line - is
+// uniform across the wave.  LONG = false: k < 227, three registers.  LONG = true: up to 623 outputs; twisted word k (k >= 227)
+// is word k - 227 of the twisted state XOR the twist of the SEEDED words k, k + 1, i.e. an output drawn 227 iterations
+// earlier: a delay line of the untempered outputs (397 words per seed in scratch memory, written and read at a uniform index:
+// 256 contiguous bytes per wave and access) replaces the 624-word state and its block twist.  CELL: the cell list in LDS.
+template <typename CELL, bool LONG>
+__global__ __launch_bounds__(64) void k_generate_mt19937_stream(uint32_t *blk, void *init_v, void *tgt_v, const uint32_t *seeds, int64_t N,
+                                                                 int S, int T, int Tt, int K, int wide, int window) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  CELL *cells = reinterpret_cast<CELL *>(smem);  // [cell][lane]
+  const int lane = threadIdx.x;
+  const int64_t n = (int64_t)blockIdx.x * kWave + lane;
+  const bool live = n < N;
   const int C = S * S;
-  const uint32_t seed = seeds[n];
-  if (C <= kMtStreamCells && window > 0) {  // uniform
-    const int lane = threadIdx.x;
-    uint32_t a0 = seed, a1 = mt_seed_step(seed, 1u);  // mt[k], mt[k + 1]
-    uint32_t b = a1;
-    for (uint32_t i = 2; i <= (uint32_t)kMtM; ++i) b = mt_seed_step(b, i);  // mt[k + 397]
-    int k = 0;
-    bool in_window = true;
-    for (int i = 0; i < C; ++i) cells[i * kWave + lane] = (unsigned char)i;
-    for (int i = C - 1; i >= 1 && in_window; --i) {
-      const uint32_t mask = mask_for((uint32_t)i);
-      uint32_t j;
-      do {
-        if (k >= window) {
-          in_window = false;
-          break;
-        }
-        j = mt_temper(b ^ mt_twist(a0, a1)) & mask;  // output k of the generator
-        a0 = a1;
-        a1 = mt_seed_step(a1, (uint32_t)(k + 2));
-        b = mt_seed_step(b, (uint32_t)(k + kMtM + 1));
-        ++k;
-      } while (j > (uint32_t)i);
-      if (in_window) {
-        const unsigned char t = cells[i * kWave + lane];
+  const uint32_t seed = seeds[live ? n : N - 1];
+  uint32_t a0 = seed, a1 = mt_seed_step(seed, 1u);  // seeded words k, k + 1
+  uint32_t b = a1;
+  for (uint32_t i = 2; i <= (uint32_t)kMtM; ++i) b = mt_seed_step(b, i);  // seeded word k + 397
+  uint32_t delay[LONG ? kMtM : 1];  // untempered outputs 0 .. 396
+  for (int i = 0; i < C; ++i) cells[i * kWave + lane] = (CELL)i;
+  int i = C - 1, k = 0;
+  for (;;) {
+    const bool active = live && i >= 1;
+    if (__ballot(active) == 0 || k >= window) break;  // uniform
+    uint32_t x = b;
+    if constexpr (LONG) {
+      if (k >= kMtStreamWindow) x = delay[k - kMtStreamWindow];
+    }
+    const uint32_t u = x ^ mt_twist(a0, a1);  // word k of the twisted state
+    if constexpr (LONG) {
+      if (k < kMtM) delay[k] = u;
+    }
+    const uint32_t y = mt_temper(u);
+    a0 = a1;
+    a1 = mt_seed_step(a1, (uint32_t)(k + 2));
+    b = mt_seed_step(b, (uint32_t)(k + kMtM + 1));
+    ++k;
+    if (active) {  // one step of the reverse Fisher-Yates shuffle, if random_interval(i) accepts this draw
+      const uint32_t j = y & mask_for((uint32_t)i);
+      if (j <= (uint32_t)i) {
+        const CELL t = cells[i * kWave + lane];
         cells[i * kWave + lane] = cells[j * kWave + lane];
         cells[j * kWave + lane] = t;
+        --i;
       }
     }
-    if (in_window) {
-      mt_store_level([&](int i) -> int { return cells[i * kWave + lane]; }, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
-      return;
-    }
   }
-  mt_level_general(seed, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
+  if (!live) return;
+  if (i >= 1)  // ran out of window before the shuffle was complete: start over in the general form
+    mt_level_general(seed, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
+  else
+    mt_store_level([&](int c) -> int { return cells[c * kWave + lane]; }, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
 }
 
 // uint8 -> float32, 16 output bytes per lane, one KiB per wave, workgroups in address order: the
@@ -1899,7 +1932,7 @@ std::atomic<int64_t> g_multi_min_boards{TS_MULTI_MIN_BOARDS};  // ts_tuning(TS_T
 std::atomic<int64_t> g_lines_lanes{0};  // ts_tuning(TS_TUNE_LINES_LANES): 0 = by tile count, 4 / 8 / 16 = forced where instantiated
 std::atomic<int64_t> g_lines_bpw{0};    // ts_tuning(TS_TUNE_LINES_BPW): 0 = policy, else boards per wave of k_lines (the other lanes idle)
 std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): INT64_MAX = policy, 0 = eighths, P = pieces of P blocks (out-of-cache launches)
-std::atomic<int64_t> g_mt_window{kMtStreamWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
+std::atomic<int64_t> g_mt_window{kMtLongWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
 std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
 std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
@@ -1997,34 +2030,26 @@ bool multi_applicable(const KArgs &a) {
 }
 #endif
 
-// k_deal: boards up to 8x8 with 9 .. 64 tiles (and targets), G lanes per board, TPL tiles per lane
-template <int S, bool EXTRAS, bool NT>
-SmallKernel deal_kernel_for(int lanes, int tpl) {
-  if constexpr (S < 4) {
-    return nullptr;
-  } else {
-    if (lanes == 4) return tpl == 4 ? k_deal<S, 4, 4, EXTRAS, NT> : nullptr;
-    if (tpl == 2) return k_deal<S, 8, 2, EXTRAS, NT>;
-    if constexpr (S >= 5) {
-      if (tpl == 4) return k_deal<S, 8, 4, EXTRAS, NT>;
-    }
-    if constexpr (S >= 6) {
-      if (tpl == 8) return k_deal<S, 8, 8, EXTRAS, NT>;
-    }
-    return nullptr;
+// k_deal: 7x7 and 8x8 boards with 9 .. 64 tiles (and targets), G lanes per board, TPL = ceil(tiles / G) tiles per lane
+template <int S, int G, bool EXTRAS, bool NT>
+SmallKernel deal_kernel_tpl(int tpl) {
+  switch (tpl) {
+    case 2: if constexpr (G == 8) return k_deal<S, G, 2, EXTRAS, NT>; else return nullptr;
+    case 3: return k_deal<S, G, 3, EXTRAS, NT>;
+    case 4: return k_deal<S, G, 4, EXTRAS, NT>;
+    case 5: return k_deal<S, G, 5, EXTRAS, NT>;
+    case 6: return k_deal<S, G, 6, EXTRAS, NT>;
+    case 7: return k_deal<S, G, 7, EXTRAS, NT>;
+    case 8: return k_deal<S, G, 8, EXTRAS, NT>;
+    default: return nullptr;
   }
 }
 
 template <bool EXTRAS, bool NT>
 SmallKernel deal_kernel(int S, int lanes, int tpl) {
-  switch (S) {
-    case 4: return deal_kernel_for<4, EXTRAS, NT>(lanes, tpl);
-    case 5: return deal_kernel_for<5, EXTRAS, NT>(lanes, tpl);
-    case 6: return deal_kernel_for<6, EXTRAS, NT>(lanes, tpl);
-    case 7: return deal_kernel_for<7, EXTRAS, NT>(lanes, tpl);
-    case 8: return deal_kernel_for<8, EXTRAS, NT>(lanes, tpl);
-    default: return nullptr;
-  }
+  if (S == 7) return lanes == 4 ? deal_kernel_tpl<7, 4, EXTRAS, NT>(tpl) : deal_kernel_tpl<7, 8, EXTRAS, NT>(tpl);
+  if (S == 8) return lanes == 4 ? deal_kernel_tpl<8, 4, EXTRAS, NT>(tpl) : deal_kernel_tpl<8, 8, EXTRAS, NT>(tpl);
+  return nullptr;
 }
 
 inline uint32_t align16(uint32_t x) { return (x + 15u) & ~15u; }
@@ -2089,22 +2114,27 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
   if (TS_OOC_WAVES > 0) return {TS_OOC_WAVES, TS_OOC_BLOCKS > 0 ? TS_OOC_BLOCKS : 0};
   if (compute_heavy) return {0, 0};
   // Round 3: with store instructions that cover whole 128-byte lines (emit_bytes_as_f32) a launch tolerates - and wants -
-  // more resident waves than before (profiles/r03_emit_edges_ab.log, r03_residency_sweep.log; blocks per CU, us per step):
-  // cfg4 7 -> 17 (134 -> 103), cfg2 4 -> 8 (139 -> 113), 4x4 at 4M boards 12 -> 14, 6x6 7 -> 10, 7x7 8 -> 14, 14x14 7 -> 18,
-  // 9x9 / 12x12 7 -> 10 / 12; very large chunks (16x16 with 8 boards per wave, 20x20 and up) are flat from 6 on.
+  // more resident waves than before (profiles/r03_emit_edges_ab.log, r03_residency_sweep.log).
+  // Round 4: re-tuned on PHYSICALLY CONTIGUOUS output buffers (the host's default beyond the Infinity Cache), which want more
+  // resident blocks than ordinary allocations did (profiles/r04_residency_contiguous.log against r04_residency_torch_allocator.log;
+  // blocks per CU round 3 -> now, us per step of a 600 MB batch): 5x5 10 -> 14 (93.1 -> 86.0), 4x4 14 -> 18 (97.2 -> 95.4),
+  // 11x11 12 -> 18 (103.7 -> 92.6), 13x13 18 -> 22 (95.7 -> 88.2), 16x16 10 -> 14 (83.7 -> 78.3), 20x20 10 -> 8 (95.2 -> 91.2),
+  // 24x24 7 -> 9, 32x32 4 -> 6; cfg2 (8) and cfg4 (18) are flat around their old values.
   if (lines_kernel) {
-    if (chunk >= 40u * 1024u) return {1, 4};
-    if (chunk >= 24u * 1024u) return {1, 7};
-    if (chunk >= 12u * 1024u) return {1, 10};
-    if (chunk >= 8u * 1024u) return {1, 18};
-    return {1, 12};
+    if (chunk >= 40u * 1024u) return {1, 6};
+    if (chunk >= 24u * 1024u) return {1, 9};
+    if (chunk >= 16u * 1024u) return {1, 8};
+    if (chunk >= 14u * 1024u) return {1, 10};
+    if (chunk >= 12u * 1024u) return {1, 14};
+    if (chunk >= 10u * 1024u) return {1, 18};   // cfg4
+    if (chunk >= 8u * 1024u) return {1, 22};
+    return {1, 18};
   }
   // k_small, half waves (32 boards per wave, see small_boards_per_wave): `chunk` is the half wave's output
   if (chunk >= 22u * 1024u) return {1, 8};                     // cfg2 (25.6 KB): 2 blocks per CU 247 us, 4: 138, 6: 120, 8: 113
   if (chunk >= 16u * 1024u) return {1, 14};                    // 7x7
-  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 10 : 12};   // 5x5, 6x6
-  if (chunk >= 4u * 1024u) return {1, 14};                     // 4x4
-  return {1, 16};  // 2x2, 1x1 (full waves; 3x3's 6.9 KB land in the branch above)
+  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 14 : 16};   // 5x5, 6x6
+  return {1, 18};                                              // 4x4 and below (full waves below 3x3)
 }
 
 // Which store instructions of a wave's chunk go out as write-back stores instead of nontemporal ones (KArgs.emit_edges):
@@ -2222,13 +2252,16 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     }
 #endif
     const int maxT = T > Tt ? T : Tt;
-    if (tfix == 0 && S >= 4 && maxT > 8 && maxT <= 64 && g_deal_enabled.load(std::memory_order_relaxed) != 0) {
-      // more than 8 tiles: a board's tiles dealt over 4 or 8 lanes (k_deal); ts_dims.lines_lanes / TS_TUNE_LINES_LANES force 4 or 8
-      int lanes = maxT <= 16 ? TS_DEAL_LANES_SMALL : 8;
+    if (tfix == 0 && S >= 7 && maxT > 8 && maxT <= 64 && g_deal_enabled.load(std::memory_order_relaxed) != 0) {
+      // 7x7 / 8x8 with more than 8 tiles: a board's tiles dealt over 4 lanes (up to TS_DEAL_LANES4_MAX tiles) or 8 (k_deal);
+      // ts_dims.lines_lanes / TS_TUNE_LINES_LANES = 4 / 8 force a form where it exists (4 lanes: up to 32 tiles).  Smaller
+      // boards stay with one lane per board: their observation is too short for a wave of 16 boards to pay for the group
+      // shuffles (6x6 / 12 tiles 78.9 us one lane, 82.8 dealt; 5x5 58.3 against 65.3 - profiles/r04_deal_ab.log)
+      int lanes = maxT <= TS_DEAL_LANES4_MAX ? 4 : 8;
       if (const int64_t forced = g_lines_lanes.load(std::memory_order_relaxed); forced == 4 || forced == 8) lanes = (int)forced;
       if (d->lines_lanes == 4 || d->lines_lanes == 8) lanes = d->lines_lanes;
-      if (maxT > 16) lanes = 8;
-      const int tpl = lanes == 4 ? 4 : maxT <= 16 ? 2 : maxT <= 32 ? 4 : 8;
+      if (maxT > 32) lanes = 8;
+      const int tpl = (maxT + lanes - 1) / lanes;
       const bool extras = a.valid || a.valid4 || a.reward || a.onehot;
       SmallKernel k = extras ? (a.nt ? deal_kernel<true, true>(S, lanes, tpl) : deal_kernel<true, false>(S, lanes, tpl))
                              : (a.nt ? deal_kernel<false, true>(S, lanes, tpl) : deal_kernel<false, false>(S, lanes, tpl));
@@ -2240,7 +2273,9 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
         a.lds_oh_off = align16(a.lds_stage_off + ((a.reward && !d->multi_color) ? (uint32_t)(bpw * Tt) : 0u));
         a.lds_wave_bytes = a.lds_oh_off + (a.onehot ? 8192u : 0u);
         const uint64_t out_pb = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
-        Residency res = ooc_residency(a.nt != 0, true, false, (uint64_t)bpw * out_pb, T);
+        // full occupancy (4-wave blocks, as many as fit): the group shuffles and the slides are a latency chain per wave, and a
+        // wave writes only 6 .. 12 KB - 8x8 / 12 tiles: 91.7 us with the large-board kernel's bound of 14 blocks per CU, 75.2 without
+        Residency res = ooc_residency(a.nt != 0, true, true, (uint64_t)bpw * out_pb, T);
         apply_launch_hint(res, d->launch_hint);
         if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
         if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
@@ -2296,7 +2331,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     if (S <= 10 && maxT <= 16) lpb = 8;
     if (S <= 10 && maxT <= 4) lpb = 4;
     if (const int64_t forced = g_lines_lanes.load(std::memory_order_relaxed); forced == 4 || forced == 8 || forced == 16) lpb = (int)forced;
-    if (d->lines_lanes) lpb = d->lines_lanes;
+    if (d->lines_lanes >= 4) lpb = d->lines_lanes;
     if (lpb == 4 && wide) lpb = 8;
     if (lpb < 16 && (maxT + lpb - 1) / lpb > 2) lpb = 16;  // instantiated: 1 or 2 tiles per lane for 4 and 8 lanes per board
     const int bpw_max = kWave / lpb;
@@ -2535,7 +2570,7 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_DEAL ? &g_deal_enabled
                                : key == TS_TUNE_MT_WINDOW ? &g_mt_window : nullptr;
   if (!knob) return -1;
-  if (key == TS_TUNE_MT_WINDOW && value > kMtStreamWindow) value = kMtStreamWindow;  // beyond it the twisted words are needed
+  if (key == TS_TUNE_MT_WINDOW && value > kMtLongWindow) value = kMtLongWindow;  // output 623 wraps around to twisted word 0
   return value >= 0 ? knob->exchange(value) : knob->load();
 }
 
@@ -2588,9 +2623,24 @@ int32_t ts_generate_mt19937(const ts_dims *dims, const ts_state *st, const uint3
   if (!st || !seeds || !st->blk || (dims->n_tiles && !st->init) || (dims->n_targets && !st->tgt)) return TS_ERR_NULL;
   const int64_t blocks = (dims->n_boards + 63) / 64;
   if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-  hipLaunchKernelGGL(k_generate_mt19937, dim3((uint32_t)blocks), dim3(64), 0, (hipStream_t)stream, (uint32_t *)st->blk,
-                     const_cast<void *>(st->init), const_cast<void *>(st->tgt), seeds, dims->n_boards, dims->size, dims->n_tiles,
-                     dims->n_targets, n_obstacles, dims->size > 16 ? 1 : 0, (int)g_mt_window.load(std::memory_order_relaxed));
+  const int window = (int)g_mt_window.load(std::memory_order_relaxed);
+  const int wide = dims->size > 16 ? 1 : 0;
+  hipStream_t hs = (hipStream_t)stream;
+  uint32_t *blk = (uint32_t *)st->blk;
+  void *init = const_cast<void *>(st->init), *tgt = const_cast<void *>(st->tgt);
+  const int S = dims->size, T = dims->n_tiles, Tt = dims->n_targets;
+  if (window > 0 && C <= kMtStreamCells)
+    hipLaunchKernelGGL((k_generate_mt19937_stream<uint8_t, false>), dim3((uint32_t)blocks), dim3(64), (size_t)C * kWave, hs, blk, init, tgt, seeds,
+                       dims->n_boards, S, T, Tt, n_obstacles, wide, window < kMtStreamWindow ? window : kMtStreamWindow);
+  else if (window > 0 && C <= 256)
+    hipLaunchKernelGGL((k_generate_mt19937_stream<uint8_t, true>), dim3((uint32_t)blocks), dim3(64), (size_t)C * kWave, hs, blk, init, tgt, seeds,
+                       dims->n_boards, S, T, Tt, n_obstacles, wide, window);
+  else if (window > 0 && C <= kMtLongCells)
+    hipLaunchKernelGGL((k_generate_mt19937_stream<uint16_t, true>), dim3((uint32_t)blocks), dim3(64), (size_t)C * kWave * 2, hs, blk, init, tgt, seeds,
+                       dims->n_boards, S, T, Tt, n_obstacles, wide, window);
+  else
+    hipLaunchKernelGGL(k_generate_mt19937_general, dim3((uint32_t)blocks), dim3(64), 0, hs, blk, init, tgt, seeds, dims->n_boards, S, T, Tt,
+                       n_obstacles, wide);
   return finish_launch();
 }
 

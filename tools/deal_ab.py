@@ -25,10 +25,9 @@ def rate(env, act, reps=20, rounds=3):
     return statistics.median(ts)
 
 
-print("   S    T    K    boards   out MB |  one lane   |  deal, policy |  deal, 8 lanes |  + hint -2 / +2 / +4 (policy lanes)      (us per step, frac of 8 TB/s)")
-for S, T, K, n in ((8, 20, 10, 651008), (8, 12, 8, 651008), (8, 9, 8, 651008), (8, 16, 8, 651008), (8, 32, 8, 651008), (8, 40, 4, 651008),
-                   (7, 12, 6, 850176), (6, 12, 4, 1048576), (6, 9, 4, 1048576), (5, 12, 3, 1048576), (5, 9, 3, 1048576), (4, 10, 2, 1048576), (4, 10, 2, 4194304),
-                   (8, 20, 10, 262144), (6, 12, 4, 262144)):
+print("   S    T    K    boards   out MB |  one lane   |  deal, policy | per lanes-per-board: us at launch_hint 0 / +4 / +8 (no effect without a bound), then with the large-board kernel's bound   (us per step, frac of 8 TB/s)")
+for S, T, K, n in ((8, 20, 10, 651008), (8, 12, 8, 651008), (8, 9, 8, 651008), (8, 16, 8, 651008), (8, 17, 8, 651008), (8, 24, 8, 651008), (8, 28, 6, 651008),
+                   (7, 12, 6, 850176), (7, 20, 4, 850176), (8, 20, 10, 262144), (7, 12, 6, 262144)):
     bps = bench.algorithmic_bytes_per_board_step(S, T, False, False)
     env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=bench.LEVEL_SEED, multi_color=True, max_steps=2**30, auto_reset=True)
     env.reset()
@@ -39,13 +38,20 @@ for S, T, K, n in ((8, 20, 10, 651008), (8, 12, 8, 651008), (8, 9, 8, 651008), (
     us = rate(env, act); row += f" {us:6.1f} {frac(us):.3f} |"
     L.ts_tuning(_cabi.TUNE_DEAL, 1)
     us = rate(env, act); row += f" {us:6.1f} {frac(us):.3f}  |"
-    env._dims.lines_lanes = 8
-    us = rate(env, act); row += f" {us:6.1f} {frac(us):.3f}   |"
+    for lanes in (4, 8):
+        if lanes == 4 and T > 32:
+            row += "      -       |"
+            continue
+        env._dims.lines_lanes = lanes
+        row += f" {lanes} lanes:"
+        for h in (0, 4, 8):
+            env._dims.launch_hint = h
+            us = rate(env, act, reps=12, rounds=2); row += f" {us:6.1f}"
+        env._dims.launch_hint = 0
+        L.ts_tuning(_cabi.TUNE_DEAL, 3)  # experiment: the large-board kernel's bound on the resident blocks
+        us = rate(env, act, reps=12, rounds=2); row += f" bounded {us:6.1f} {frac(us):.3f} |"
+        L.ts_tuning(_cabi.TUNE_DEAL, 1)
     env._dims.lines_lanes = 0
-    for h in (-2, 2, 4):
-        env._dims.launch_hint = h
-        us = rate(env, act, reps=12, rounds=2); row += f" {us:6.1f}"
-    env._dims.launch_hint = 0
     print(row, flush=True)
     del env, act
     torch.cuda.empty_cache()
