@@ -108,9 +108,9 @@ typedef struct ts_dims {
                         * (The field was `reserved`, must-be-zero, before ABI v3.) */
   int32_t emit_edges;  /* ABI v4.  0 = policy; 1 + e (e = 0 .. 3): bit 0 / bit 1 of e = the first / last store instruction
                         * of every wave's chunk of observation is a write-back store instead of a nontemporal one. */
-  int32_t lines_lanes; /* ABI v4.  0 = policy; 4 / 8 / 16 = lanes per board of the kernels that deal a board over several
-                        * lanes (boards above 8x8; 7x7 / 8x8 with more than 8 tiles: 4 / 8), where that form exists for the
-                        * shape (else the policy's choice is taken). */
+  int32_t lines_lanes; /* ABI v4.  0 = policy; 4 / 8 / 16 / 32 = lanes per board of the kernels that deal a board over several
+                        * lanes (boards above 8x8 - 32 only above 16x16; 7x7 / 8x8 with more than 8 tiles: 4 / 8), where that
+                        * form exists for the shape (else the policy's choice is taken). */
   int32_t xcd_piece;   /* ABI v4.  0 = policy; 1 = the blocks that share an XCD get one contiguous eighth of the batch;
                         * P >= 2 = pieces of P consecutive blocks per XCD, dealt round-robin over the eight XCDs (the eight
                         * write fronts then stay close together).  The policy - pieces of 16 / 32 / 64 by kernel and chunk -
@@ -248,9 +248,10 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
  *       blocks, bounded residency, half waves (different instantiations of the same kernels).  Default
  *       268435456 (the 256 MiB Infinity Cache of MI355X); 0 = every launch takes the out-of-cache kernels
  *       (the parity tests use this to cover them at small batch sizes).
- *   TS_TUNE_LINES_LANES  lanes per board of the kernel for boards above 8x8: 0 (default) = by tile count
- *       (4 lanes up to 4 tiles on boards up to 16x16, 8 lanes up to 16 tiles, else 16); 4 / 8 / 16 = forced
- *       where that form exists (at most two tiles per lane with 4 and 8 lanes; 8 lanes at least above 16x16).
+ *   TS_TUNE_LINES_LANES  lanes per board of the kernel for boards above 8x8: 0 (default) = by size and tile count
+ *       (up to 10x10 4 lanes up to 4 tiles; up to 13x13 8 lanes up to 16 tiles; from 20x20 on 32 lanes; else 16);
+ *       4 / 8 / 16 / 32 = forced where that form exists (at most two tiles per lane with 4 and 8 lanes; 8 lanes at
+ *       least and 32 only above 16x16).
  *   TS_TUNE_LINES_BPW  boards per wave of that kernel: 0 (default) = the policy (64 / lanes per board, fewer for
  *       boards whose observation is large: a wave's contiguous chunk of output should stay near 10 KB);
  *       1 .. 64 / lanes = forced (the remaining lanes idle; ignored where 12 * S * S * value is not a multiple of 16).
@@ -277,6 +278,9 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
                              * seed that needs more than `value` outputs (default and maximum 623; boards up to 10x10: at most 227)
                              * takes the general form.  0 = always the general form.  Results never differ; tests shrink the
                              * window to exercise the hand-over. */
+#define TS_TUNE_SMALL_BPW 8 /* boards per wave of the one-lane-per-board kernel's register forms beyond the Infinity Cache: 0 (default)
+                             * = the policy (the largest of 64 / 32 / 16 whose chunk of observation stays within 14 KB); 16 / 32 / 64 =
+                             * forced (the remaining lanes idle) */
 int64_t ts_tuning(int32_t key, int64_t value);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */

@@ -234,7 +234,12 @@ def test_generator_and_actions_match_twin(torch_cuda, oracle):
 
 
 @pytest.mark.parametrize("S,T,K,N,onehot", [(4, 2, 2, 1 << 20, False), (5, 2, 3, 1 << 20, True), (15, 32, 24, 1 << 18, False),
-                                            (4, 2, 2, 1 << 22, False), (6, 3, 4, 1 << 20, False)])
+                                            (4, 2, 2, 1 << 22, False), (6, 3, 4, 1 << 20, False),
+                                            # beyond the cache with the round-4 launch forms: quarter waves (7x7: their chunks start off a
+                                            # 128-byte line; 8x8), tiles dealt over four lanes (8x8 / 12 tiles), 32 lanes per board (24x24),
+                                            # one board per wave (32x32)
+                                            (7, 5, 6, 600_000, False), (8, 4, 8, 450_000, False), (8, 12, 8, 450_000, False),
+                                            (24, 6, 40, 50_000, False), (32, 4, 100, 30_000, False)])
 def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N, onehot):
     """BASELINE.json configs 1, 2 and 4 at full size, the 4M-board sibling of config 1 and a 6x6
     batch beyond the Infinity Cache (two-pass image in half waves): a complete oracle replay of every
@@ -482,12 +487,13 @@ def test_large_batches_vs_oracle(torch_cuda, oracle, S, T, K, mc, N):
         assert np.array_equal(env.encode_onehot().cpu().numpy(), ref.encode_onehot())
 
 
-@pytest.mark.parametrize("lanes", [4, 8, 16])
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32])
 @pytest.mark.parametrize("S,T,Tt,K,mc,N", [(9, 4, 4, 9, True, 1031), (12, 8, 8, 16, False, 517), (16, 3, 3, 30, True, 259), (20, 6, 6, 30, False, 131),
                                            (32, 2, 2, 100, True, 37), (15, 2, 1, 24, True, 300), (13, 1, 3, 30, False, 222), (11, 7, 7, 5, False, 401),
-                                           (10, 5, 8, 3, True, 333), (24, 16, 16, 60, True, 67)])
+                                           (10, 5, 8, 3, True, 333), (24, 16, 16, 60, True, 67), (17, 40, 40, 10, False, 99), (28, 100, 90, 30, True, 35),
+                                           (32, 255, 255, 50, False, 11), (21, 1, 1, 0, True, 130)])
 def test_lines_kernel_lanes_per_board_forced(torch_cuda, oracle, lanes, S, T, Tt, K, mc, N):
-    """k_lines deals a board's lines and tiles over 4, 8 or 16 lanes (the policy picks by tile count): every form that
+    """k_lines deals a board's lines and tiles over 4, 8, 16 or (above 16x16) 32 lanes (the policy picks by size and tile count): every form that
     exists for a shape must give the oracle's outputs, optional outputs included, cache-resident and out-of-cache kernels."""
     torch = torch_cuda
     from tiler_slider_amd import VecTilerSliderEnv, _cabi

@@ -280,7 +280,8 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
       // in the store-only probe) even though the next instruction of the same wave completes the line.  Here instruction k
       // stores units 64 k + l - m: whole lines, except the first and last line of the chunk, which the neighbouring
       // waves share; those pieces go out as plain (write-back) stores, so that the two halves meet in the XCD's L2.
-      const int m = ANY_START ? (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u) : 0;  // k_small: chunks start on a line
+      // (k_small's chunks start on a line except for quarter waves of odd board sizes - 7x7: 9,408 B; computing m costs two instructions)
+      const int m = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7u);
       const int total = nf4 + m, iters = (total + kWave - 1) >> 6;
       const int last_line = total >> 3;
       const bool tail_shared = (total & 7) != 0;
@@ -1314,7 +1315,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   constexpr int R = NLN / G;           // lines per lane
   constexpr int W2 = WIDE ? 2 : 1;     // words per line in the obstacle table (row and column masks apart above 16x16)
   constexpr int REC = lines_record_words(WIDE);
-  static_assert(G == 4 || G == 8 || G == 16, "lanes per board");
+  static_assert(G == 4 || G == 8 || G == 16 || (G == 32 && WIDE), "lanes per board");
   auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
   auto mul_s = [&](int x) -> int { return (int)__umul24((uint32_t)x, (uint32_t)S); };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1915,6 +1916,10 @@ __global__ __launch_bounds__(256) void k_expand_u8(const uint32_t *src, f32x4 *d
   if (q < n4) store_f4<NT>(dst + q, bytes_to_f4(src[q]));
 }
 
+// (Round 4 tried the step kernels' store pattern here - one-wave blocks, a private 12 KiB chunk per wave, XCD pieces, bounded
+// residency, write-back edge stores, all loads of a chunk issued first: 8,388,608 4x4 boards, 403 MB in / 1.6 GB out, 364 us
+// against 356 with this kernel.  The launch reads a byte for every four it writes: it sits at the mixed read / write rate of the
+// memory system - 5.6 TB/s, 0.9 of the guide's 6.29 TB/s copy ceiling - not at the write-only rates of the step kernels.)
 __global__ void k_expand_tail(const uint8_t *src, float *dst) {
   if (threadIdx.x == 0) *dst = (float)*src;
 }
@@ -1933,6 +1938,7 @@ std::atomic<int64_t> g_lines_lanes{0};  // ts_tuning(TS_TUNE_LINES_LANES): 0 = b
 std::atomic<int64_t> g_lines_bpw{0};    // ts_tuning(TS_TUNE_LINES_BPW): 0 = policy, else boards per wave of k_lines (the other lanes idle)
 std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): INT64_MAX = policy, 0 = eighths, P = pieces of P blocks (out-of-cache launches)
 std::atomic<int64_t> g_mt_window{kMtLongWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
+std::atomic<int64_t> g_small_bpw{0};  // ts_tuning(TS_TUNE_SMALL_BPW): 0 = policy, 16 / 32 / 64 = boards per wave of k_small's register forms beyond the cache
 std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
 std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
@@ -1940,7 +1946,7 @@ std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1
 int32_t check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
   if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 || d->emit_edges < 0 || d->emit_edges > 4 || d->xcd_piece < 0 || d->xcd_piece > (1 << 20) ||
-      (d->lines_lanes != 0 && d->lines_lanes != 4 && d->lines_lanes != 8 && d->lines_lanes != 16) ||
+      (d->lines_lanes != 0 && d->lines_lanes != 4 && d->lines_lanes != 8 && d->lines_lanes != 16 && d->lines_lanes != 32) ||
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;
   if (d->size > TS_MAX_SIZE || d->n_tiles > TS_MAX_TILES || d->n_targets > TS_MAX_TILES) return TS_ERR_LIMIT;
@@ -2133,8 +2139,9 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
   // k_small, half waves (32 boards per wave, see small_boards_per_wave): `chunk` is the half wave's output
   if (chunk >= 22u * 1024u) return {1, 8};                     // cfg2 (25.6 KB): 2 blocks per CU 247 us, 4: 138, 6: 120, 8: 113
   if (chunk >= 16u * 1024u) return {1, 14};                    // 7x7
-  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 14 : 16};   // 5x5, 6x6
-  return {1, 18};                                              // 4x4 and below (full waves below 3x3)
+  if (chunk >= 11u * 1024u) return {1, 18};                    // 4x4 (full waves), 6x6, 8x8 (quarter waves: 87.8 us with 14, 82.8 with 18)
+  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 14 : 16};   // 5x5, 7x7
+  return {1, 18};                                              // 3x3 and below
 }
 
 // Which store instructions of a wave's chunk go out as write-back stores instead of nontemporal ones (KArgs.emit_edges):
@@ -2162,20 +2169,27 @@ uint32_t piece_policy(bool lines_kernel, uint64_t chunk) {
 #endif
 }
 
-// Boards per wave of k_small.  Beyond the Infinity Cache the register-path kernels run HALF waves —
-// 32 boards, the upper lanes idle — once a full wave would write 8 KB or more: the transition
-// arithmetic is a small part of such a launch (7.6 of 33 us at cfg1), while halving every wave's
-// chunk of output at the same bytes in flight per CU is worth 3-12 % (4x4 at 4M boards 126 -> 113 us,
-// cfg2 132 -> 121, 6x6 77 -> 68; profiles/r02_ooc_residency_sweep.log).
-int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t chunk_full_wave, uint64_t state_bytes) {
+// Boards per wave of k_small.  Beyond the Infinity Cache the register-path kernels run PARTIAL waves - 32 or 16 boards, the
+// upper lanes idle: the transition arithmetic is a small part of such a launch (7.6 of 33 us at cfg1), while what a wave
+// writes in one piece decides the write rate (round 2: half waves from 8 KB per full wave on, 3-12 %).  Round 4, on physically
+// contiguous output buffers (profiles/r04_small_boards_per_wave.log, r04_big_chunk_probe.log): the optimum is a chunk of
+// 9 .. 14 KB of observation per wave, whatever the board - 4x4 FULL waves (12.3 KB: 95.5 -> 90.5 us for 600 MB), 5x5 and 6x6
+// half waves (9.6 / 13.8 KB), 7x7 and 8x8 QUARTER waves (9.4 / 12.3 KB: 7x7 98.9 -> 83.2, 8x8 with 4 tiles 95.5 -> 82.8,
+// with 8 tiles 101.8 -> 82.8: 0.80 -> 0.96 of the HBM roofline).  `primary`: bytes per board of the launch's first large
+// stream (float32 observation, else uint8 observation, else one-hot planes).
+int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primary, uint64_t state_bytes) {
 #if TS_SMALL_OOC_BPW > 0
   return (out_of_cache && register_path) ? TS_SMALL_OOC_BPW : kWave;
 #else
-  // Once the STATE of the batch no longer fits the Infinity Cache either (tens of millions of boards) a half wave's 32-byte
+  if (!out_of_cache || !register_path || TS_OOC_WAVES == 0) return kWave;
+  // Once the STATE of the batch no longer fits the Infinity Cache either (tens of millions of boards) a partial wave's short
   // pieces of every state row cost more than its shorter chunk wins: 4x4 at 64M boards 3.35 ms with half waves, 2.57 with full
   // ones (at 16M boards, 300 MB of state, half waves still win: 592 vs 722 us).
   if (state_bytes > (640ull << 20)) return kWave;
-  return (out_of_cache && register_path && chunk_full_wave >= 8u * 1024u && TS_OOC_WAVES != 0) ? 32 : kWave;
+  if (const int64_t forced = g_small_bpw.load(std::memory_order_relaxed); forced == 16 || forced == 32 || forced == 64) return (int)forced;
+  for (int bpw = kWave; bpw > 16; bpw >>= 1)
+    if (primary * (uint64_t)bpw <= 14u * 1024u) return bpw;
+  return 16;
 #endif
 }
 
@@ -2295,7 +2309,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_oh_off = a.lds_stage_off + (need_stage ? align16((uint32_t)(kWave * (T + Tt))) + (need_masks ? 3u * kWave * 8u : 0u) : 0u);
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
-    a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, (uint64_t)kWave * out_per_board,
+    a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, a.obs ? 12ull * C : a.obs_u8 ? 3ull * C : 4ull * C * a.onehot_ch,
                                             (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7));
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
@@ -2327,12 +2341,18 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const int maxT = T > Tt ? T : Tt;
     // profiles/r03_lines_lanes_ab.log: 9x9 96 -> 89 us with 4 lanes, 10x10 / 5 tiles 83 -> 77 with 8; from 12x12 on the
     // 16-lane form wins again (its chunk per wave is already 7 KB and more), above 16x16 always
+    // Round 4, on physically contiguous output buffers (profiles/r04_lines_lanes_sweep.log, r04_lines_bpw_sweep.log): 8 lanes win up
+    // to 13x13 (11x11 94.0 -> 85.6 us, 12x12 97.4 -> 87.7, 13x13 91.0 -> 82.2); from 20x20 on a wave's chunk of four boards
+    // (19 .. 49 KB) is what limits the launch - the store-only probe writes private 49,152-B chunks at 5.8 TB/s at best and
+    // 12,288-B chunks at 7.5 (profiles/r04_big_chunk_probe.log) - so a board gets 32 lanes, one line each, and a wave two boards.
     int lpb = 16;
-    if (S <= 10 && maxT <= 16) lpb = 8;
+    if (S <= 13 && maxT <= 16) lpb = 8;
     if (S <= 10 && maxT <= 4) lpb = 4;
-    if (const int64_t forced = g_lines_lanes.load(std::memory_order_relaxed); forced == 4 || forced == 8 || forced == 16) lpb = (int)forced;
+    if (S >= 20) lpb = 32;
+    if (const int64_t forced = g_lines_lanes.load(std::memory_order_relaxed); forced == 4 || forced == 8 || forced == 16 || forced == 32) lpb = (int)forced;
     if (d->lines_lanes >= 4) lpb = d->lines_lanes;
     if (lpb == 4 && wide) lpb = 8;
+    if (lpb == 32 && (!wide || (S & 1))) lpb = 16;  // (two boards of an odd size per wave would start odd waves' chunks off a 16-byte boundary)
     if (lpb < 16 && (maxT + lpb - 1) / lpb > 2) lpb = 16;  // instantiated: 1 or 2 tiles per lane for 4 and 8 lanes per board
     const int bpw_max = kWave / lpb;
     const int per_lane = (maxT + lpb - 1) / lpb;
@@ -2346,6 +2366,11 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_wave_bytes = align16(a.lds_oh_off) + (a.onehot ? 8192u : 0u) + TS_LINES_LDS_PAD;
     a.lds_oh_off = align16(a.lds_oh_off);
     a.bpw = (a.nt && TS_LINES_OOC_BPW > 0 && TS_LINES_OOC_BPW <= bpw_max) ? TS_LINES_OOC_BPW : (uint32_t)bpw_max;
+    // 28x28 and up with few tiles, beyond the Infinity Cache: ONE board per wave (the upper 32 lanes idle through the slide and
+    // stream the image out with the others) - a wave's chunk is then 9.4 .. 12.3 KB instead of 18.8 .. 24.6: 28x28 / 8 tiles
+    // 92.2 -> 79.9 us, 32x32 / 4 tiles 91.1 -> 81.3; with 32 tiles the slide's idle lanes cost what the shorter chunk wins
+    // (87.8 -> 91.4: stays at two).  profiles/r04_lines_bpw_sweep_32lanes.log
+    if (a.nt && lpb == 32 && S >= 28 && maxT <= 16) a.bpw = 1;  // (S is even here: 12 * C is a multiple of 16)
     // (a wave's chunk of float32 output must start on a 16-byte boundary: 12 * C * bpw % 16 == 0)
     if (const int64_t forced = g_lines_bpw.load(std::memory_order_relaxed); forced >= 1 && forced <= bpw_max && (3 * C * forced) % 4 == 0) a.bpw = (uint32_t)forced;
     Residency res = ooc_residency(a.nt != 0, true, false,
@@ -2381,6 +2406,14 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
         case 8: k = pick(integral_constant<int, 16>{}, integral_constant<int, 8>{}); break;
         default: k = pick(integral_constant<int, 16>{}, integral_constant<int, 16>{}); break;
       }
+    } else if (lpb == 32) {  // boards above 16x16 only; at most 8 tiles per lane (255 / 32)
+      auto pick32 = [&](auto tpl_c) -> LinesKernel {
+        constexpr int TPLC = decltype(tpl_c)::value;
+        if (lines_extras) return a.nt ? k_lines<true, 32, TPLC, true, true> : k_lines<true, 32, TPLC, false, true>;
+        return a.nt ? k_lines<true, 32, TPLC, true, false> : k_lines<true, 32, TPLC, false, false>;
+      };
+      k = tpl == 1 ? pick32(integral_constant<int, 1>{}) : tpl == 2 ? pick32(integral_constant<int, 2>{})
+          : tpl == 4 ? pick32(integral_constant<int, 4>{}) : pick32(integral_constant<int, 8>{});
     } else if (lpb == 8) {
       k = tpl == 1 ? pick(integral_constant<int, 8>{}, integral_constant<int, 1>{}) : pick(integral_constant<int, 8>{}, integral_constant<int, 2>{});
     } else {
@@ -2568,7 +2601,8 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_EMIT_EDGES ? &g_emit_edges
                                : key == TS_TUNE_XCD_PIECE ? &g_xcd_piece
                                : key == TS_TUNE_DEAL ? &g_deal_enabled
-                               : key == TS_TUNE_MT_WINDOW ? &g_mt_window : nullptr;
+                               : key == TS_TUNE_MT_WINDOW ? &g_mt_window
+                               : key == TS_TUNE_SMALL_BPW ? &g_small_bpw : nullptr;
   if (!knob) return -1;
   if (key == TS_TUNE_MT_WINDOW && value > kMtLongWindow) value = kMtLongWindow;  // output 623 wraps around to twisted word 0
   return value >= 0 ? knob->exchange(value) : knob->load();

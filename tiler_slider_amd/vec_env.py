@@ -224,6 +224,7 @@ class VecTilerSliderEnv:
                with_onehot, with_valid_moves, obs_dtype="float32", host_mapped=False, obs_buffers=1, placement_trials=0,
                output_memory="contiguous"):
         L = _cabi.lib()  # raises when the HIP library is missing: no fallback
+        self._fns = {}
         self.device = _resolve_device(device)
         self.host_mapped = bool(host_mapped)
         self.size, self.multi_color, self.max_steps = int(size), bool(multi_color), int(max_steps)
@@ -618,9 +619,18 @@ class VecTilerSliderEnv:
         return self._stage_actions(torch.tensor(vals, dtype=torch.uint8))
 
     def _call(self, name, *args):
-        with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            _cabi.check(getattr(_cabi.lib(), name)(*args, stream), name)
+        """One C-ABI call on the current stream of the environment's device.  (The device context manager is entered only when
+        another device is current: with it a small launch - ts_valid_moves4 takes 5 us on the GPU - cost three times its kernel.)"""
+        fn = self._fns.get(name)
+        if fn is None:
+            fn = self._fns[name] = getattr(_cabi.lib(), name)
+        if torch.cuda.current_device() == self.device.index:
+            rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
+        else:
+            with torch.cuda.device(self.device):
+                rc = fn(*args, torch.cuda.current_stream(self.device).cuda_stream)
+        if rc:
+            _cabi.check(rc, name)
 
     def _require_open(self):
         if self._closed:

@@ -10,17 +10,18 @@ SHAPES = [(3, 1, 0), (4, 2, 2), (4, 4, 2), (5, 2, 3), (5, 6, 3), (6, 3, 4), (7, 
           (10, 5, 10), (11, 6, 8), (12, 8, 16), (13, 3, 10), (14, 20, 20), (15, 32, 24), (16, 4, 24), (16, 16, 24), (20, 1, 1), (20, 10, 40), (24, 30, 60),
           (32, 4, 100), (32, 32, 100)]
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+print(f"# static launch policy, output_memory={os.environ.get('TS_SWEEP_MEM', 'contiguous')}")
 print("   S    T    K    boards   out MB    us/step   steps/s    alg GB/s   % of 8 TB/s")
 for S, T, K in SHAPES:
     n = max(4096, min(1 << 20, (500_000_000 // (12 * S * S)) // 256 * 256))
     env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=3, multi_color=True, max_steps=2**30,
-                                   auto_reset=True, placement_trials=int(os.environ.get('TS_SWEEP_TRIALS', '0')))
+                                   auto_reset=True, placement_trials=int(os.environ.get('TS_SWEEP_TRIALS', '0')), output_memory=os.environ.get('TS_SWEEP_MEM', 'contiguous'))
     env.reset()
     act = torch.randint(0, 4, (n,), dtype=torch.uint8, device=env.device)
     def timed():
         ts = []
         for r in range(4):
-            for i in range(3):
+            for i in range(3 if r else 60):  # the first round also ramps the clocks up after the host-side set-up
                 env.step_async(act)
             e0.record()
             for i in range(20):
