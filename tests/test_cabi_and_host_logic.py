@@ -61,9 +61,9 @@ def test_argument_validation_precedes_any_launch():
         assert L.ts_check_dims(C.byref(bad)) == want
     for hint in (-8, -1, 1, 8):  # launch_hint: speed only
         assert L.ts_check_dims(C.byref(_cabi.Dims(8, 4, 2, 2, 0, 100, hint))) == _cabi.OK
-    # the other per-call policy fields of ABI v4: emit_edges 0 .. 4, lines_lanes 0 / 4 / 8 / 16
-    for edges, lanes, want in ((0, 0, _cabi.OK), (4, 16, _cabi.OK), (1, 4, _cabi.OK), (3, 8, _cabi.OK), (5, 0, _cabi.ERR_DIMS), (-1, 0, _cabi.ERR_DIMS),
-                               (0, 2, _cabi.ERR_DIMS), (0, 32, _cabi.ERR_DIMS), (0, -4, _cabi.ERR_DIMS)):
+    # the other per-call policy fields of ABI v4: emit_edges 0 .. 4, lines_lanes 0 / 4 / 8 / 16 / 32
+    for edges, lanes, want in ((0, 0, _cabi.OK), (4, 16, _cabi.OK), (1, 4, _cabi.OK), (3, 8, _cabi.OK), (0, 32, _cabi.OK), (5, 0, _cabi.ERR_DIMS),
+                               (-1, 0, _cabi.ERR_DIMS), (0, 2, _cabi.ERR_DIMS), (0, 64, _cabi.ERR_DIMS), (0, -4, _cabi.ERR_DIMS)):
         assert L.ts_check_dims(C.byref(_cabi.Dims(8, 12, 2, 2, 0, 100, 0, edges, lanes))) == want, (edges, lanes)
     for piece, want in ((0, _cabi.OK), (1, _cabi.OK), (64, _cabi.OK), (-1, _cabi.ERR_DIMS), ((1 << 20) + 1, _cabi.ERR_DIMS)):
         assert L.ts_check_dims(C.byref(_cabi.Dims(8, 12, 2, 2, 0, 100, 0, 0, 0, piece))) == want, piece
