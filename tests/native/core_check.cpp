@@ -55,6 +55,18 @@ static long check_bitboard(int boards) {
       if (L.blocked[p]) blk |= M(1) << p;
     for (int i = 0; i < L.T; ++i) occ |= M(1) << (L.rows[i] * S + L.cols[i]);
     const uint32_t vm = ts::valid_mask<S>(occ, blk);  // legality mask by free-neighbour tests
+    if constexpr (S == 8) {  // the byte-per-line formulation of the kernel that deals an 8x8 board's tiles over several lanes
+      const uint64_t bt = ts::transpose8((uint64_t)blk), ot = ts::transpose8((uint64_t)occ);
+      for (int d = 0; d < 4; ++d)
+        for (int i = 0; i < L.T; ++i) {
+          int r = L.rows[i], c = L.cols[i];
+          ts::slide_rc8<S>(r, c, (uint64_t)blk, (uint64_t)occ, bt, ot, d);
+          if (r * S + c != ts::slide_cell<S>(L.rows[i] * S + L.cols[i], occ, blk, d)) {
+            if (bad < 5) std::fprintf(stderr, "slide_rc8 S=%d dir=%d tile=%d\n", S, d, i);
+            ++bad;
+          }
+        }
+    }
     for (int d = 0; d < 4; ++d) {
       std::vector<int32_t> r = L.rows, c = L.cols;
       tso_move(S, L.blocked.data(), L.T, r.data(), c.data(), 0, nullptr, nullptr, 0, d);

@@ -247,7 +247,7 @@ __device__ __forceinline__ void store_f4(f32x4 *dst, f32x4 v) {
 // `dst` is 16-B aligned; img is 16-B aligned.  NT (nontemporal stores) is a template parameter in
 // k_small / k_lines: the cache-resident and the out-of-cache launch are different instantiations,
 // so a profile lists them as different kernels.
-template <bool NT, bool ANY_START = false>
+template <bool NT, bool ANY_START = false, int UNROLL = TS_EMIT_UNROLL>
 __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, float *dst, int nfl, int lane, uint32_t edges = 0) {
   const int nf4 = nfl >> 2;
   const uint32_t *w = reinterpret_cast<const uint32_t *>(img);
@@ -303,7 +303,7 @@ __device__ __forceinline__ void emit_bytes_as_f32(const unsigned char *img, floa
       edge(0, (edges & 1u) != 0 || TS_EMIT_EDGE_PLAIN);
       const uint32_t *wm = w - m;
       f32x4 *dm = d4 - m;
-#pragma unroll TS_EMIT_UNROLL
+#pragma unroll UNROLL
       for (int u = kWave + lane; u < (iters - 1) * kWave; u += kWave) __builtin_nontemporal_store(bytes_to_f4(wm[u]), &dm[u]);
       if (iters > 1) edge(iters - 1, (edges & 2u) != 0 || TS_EMIT_EDGE_PLAIN);
 #else
@@ -1039,15 +1039,19 @@ __device__ __forceinline__ M group_or(M v) {
   return v;
 }
 
+// (second launch bound = waves per SIMD the register allocation must admit: the kernel is a latency chain per wave and wants
+// all eight.  At 8x8 it fits 64 VGPRs without spilling up to seven tiles per lane once the emit loop is unrolled by 4 instead
+// of 8; 7x7 (packed-bitboard slide) keeps the compiler's own choice.)
 template <int S, int G, int TPL, bool EXTRAS, bool NT>
-__global__ __launch_bounds__(256) void k_deal(const KArgs a) {
+__global__ __launch_bounds__(256, (S == 8 && TPL <= 7 && !EXTRAS ? 8 : 1)) void k_deal(const KArgs a) {
+  static_assert(sizeof(typename ts::Bitboard<S>::mask_t) == 8, "k_deal: 64-bit boards (7x7, 8x8)");
   using BB = ts::Bitboard<S>;
   using M = typename BB::mask_t;
   constexpr int C = BB::C, BPW = kWave / G;
   constexpr M kFull = C == 64 ? ~M(0) : (M(1) << (C & 63)) - 1;
   constexpr bool kChunkOnLine = (12 * C * BPW) % 128 == 0;  // a wave's chunk of observation starts on a 128-byte line
   constexpr int kU8Vec = (3 * C * BPW) % 16 == 0 ? 16 : 4;
-  static_assert(G == 4 || G == 8, "lanes per board");
+  static_assert((G == 4 || G == 8) && S >= 7, "lanes per board; the stride-8 slide is for 7x7 and 8x8");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x >> 6;
@@ -1111,31 +1115,55 @@ __global__ __launch_bounds__(256) void k_deal(const KArgs a) {
   }
 
   // ---- pre-move occupancy of the whole board: own tiles, then OR over the group ----
-  M occ = 0;
+  int pr[TPL], pc[TPL], tr[TPL], tc[TPL];
+  uint64_t occ = 0, tgm = 0;
 #pragma unroll
   for (int k = 0; k < TPL; ++k) {
     p[k] = min(p[k], C - 1);  // clamp: malformed ids stay in-board
     tg[k] = min(tg[k], C - 1);
-    occ |= hasT[k] ? M(1) << p[k] : M(0);
+    pr[k] = p[k] / S;
+    pc[k] = p[k] - pr[k] * S;
+    tr[k] = tg[k] / S;
+    tc[k] = tg[k] - tr[k] * S;
+    occ |= hasT[k] ? 1ull << p[k] : 0ull;
+    tgm |= hasG[k] ? 1ull << tg[k] : 0ull;
   }
   occ = group_or<G>(occ);
+  tgm = group_or<G>(tgm);
 
   // ---- slide (state.py:120-170) ----
-  M occ2 = 0, tgm = 0;
+  // 8x8: the packed bitboard IS the stride-8 layout (bit 8 r + c); with its transpose a tile's line - its row for LEFT / RIGHT,
+  // its column for UP / DOWN - is ONE BYTE and the slide a 32-bit slide_line (ts_core.h: slide_rc8): ~25 vector instructions per
+  // tile plus two transposes per lane, where the packed-bitboard form (slide_cell, 64-bit masks) costs ~90 per tile: 8x8 with 20
+  // tiles 85.7 -> 82 us, 28 tiles 94.0 -> 87.  7x7 keeps slide_cell: converting its stride-7 board costs more than it saves.
+  uint64_t blkT = 0, occT = 0;
+  if constexpr (S == 8) {
+    blkT = ts::transpose8((uint64_t)blk);
+    occT = ts::transpose8(occ);
+  }
+  uint64_t occ2 = 0;
   bool same = true, ordered = true;
   const bool store_pos = live && kind != 1;
 #pragma unroll
   for (int k = 0; k < TPL; ++k) {
-    const int q = kind == 0 ? ts::slide_cell<S>(p[k], occ, blk, dir) : p[k];
+    int r = pr[k], c = pc[k], q = p[k];
+    if constexpr (S == 8) {
+      if (kind == 0) ts::slide_rc8<S>(r, c, (uint64_t)blk, occ, blkT, occT, dir);
+      q = r * S + c;
+    } else {
+      if (kind == 0) q = ts::slide_cell<S>(p[k], (M)occ, blk, dir);
+      r = q / S;
+      c = q - r * S;
+    }
     same &= (q == p[k]) | !hasT[k];
     ordered &= (q == tg[k]) | !(hasT[k] && hasG[k]);
-    occ2 |= hasT[k] ? M(1) << q : M(0);
-    tgm |= hasG[k] ? M(1) << tg[k] : M(0);
+    occ2 |= hasT[k] ? 1ull << q : 0ull;
     if (store_pos && hasT[k]) a.pos[(int64_t)(j + k * G) * N + n] = (uint8_t)q;
     p[k] = q;
+    pr[k] = r;
+    pc[k] = c;
   }
   occ2 = group_or<G>(occ2);
-  tgm = group_or<G>(tgm);
   const bool all_same = (__ballot(same) & gmask) == gmask;
   const bool all_ordered = (T == Tt) && ((__ballot(ordered) & gmask) == gmask);
   const bool won = mc ? all_ordered : (occ2 == tgm);  // state.py:172-186
@@ -1160,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_deal(const KArgs a) {
   if constexpr (EXTRAS) {
     // ---- legality mask of the post-move board (environment.py:149-171): a free neighbour in the move's direction ----
     if (a.valid || a.valid4) {
-      const uint32_t vm = ts::valid_mask<S>(occ2, blk);
+      const uint32_t vm = ts::valid_mask<S>((M)occ2, blk);
       if (live && j == 0 && a.valid) a.valid[n] = (uint8_t)vm;
       if (live && j == 0 && a.valid4) reinterpret_cast<uint32_t *>(a.valid4)[n] = spread_valid(vm);
     }
@@ -1170,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_deal(const KArgs a) {
       if (mc) {
 #pragma unroll
         for (int k = 0; k < TPL; ++k)
-          sum += (hasT[k] && hasG[k]) ? abs(p[k] / S - tg[k] / S) + abs(p[k] % S - tg[k] % S) : 0;
+          sum += (hasT[k] && hasG[k]) ? abs(pr[k] - tr[k]) + abs(pc[k] - tc[k]) : 0;
       } else if (Tt > 0) {
         unsigned char *tc0 = tcells + (size_t)g * Tt;
 #pragma unroll
@@ -1182,7 +1210,8 @@ __global__ __launch_bounds__(256) void k_deal(const KArgs a) {
           int best = 1 << 30;
           for (int t = 0; t < Tt; ++t) {
             const int y = tc0[t];
-            const int dist = abs(p[k] / S - y / S) + abs(p[k] % S - y % S);
+            const int yr = y / S;
+            const int dist = abs(pr[k] - yr) + abs(pc[k] - (y - yr * S));
             best = dist < best ? dist : best;
           }
           sum += hasT[k] ? best : 0;
@@ -1234,7 +1263,8 @@ __global__ __launch_bounds__(256) void k_deal(const KArgs a) {
       }
     }
     wave_sync();
-    if (a.obs) emit_bytes_as_f32<NT, !kChunkOnLine>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+    // (unrolled by 4: eight conversions in flight cost 16 more VGPRs than this kernel's eight waves per SIMD leave)
+    if (a.obs) emit_bytes_as_f32<NT, !kChunkOnLine, 4>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
     if (a.obs_u8) emit_bytes_raw<kU8Vec, NT>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 
@@ -2177,18 +2207,23 @@ uint32_t piece_policy(bool lines_kernel, uint64_t chunk) {
 // half waves (9.6 / 13.8 KB), 7x7 and 8x8 QUARTER waves (9.4 / 12.3 KB: 7x7 98.9 -> 83.2, 8x8 with 4 tiles 95.5 -> 82.8,
 // with 8 tiles 101.8 -> 82.8: 0.80 -> 0.96 of the HBM roofline).  `primary`: bytes per board of the launch's first large
 // stream (float32 observation, else uint8 observation, else one-hot planes).
-int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primary, uint64_t state_bytes) {
+int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primary, uint64_t state_bytes, uint64_t n_boards) {
 #if TS_SMALL_OOC_BPW > 0
   return (out_of_cache && register_path) ? TS_SMALL_OOC_BPW : kWave;
 #else
-  if (!out_of_cache || !register_path || TS_OOC_WAVES == 0) return kWave;
+  if (!out_of_cache || !register_path || TS_OOC_WAVES == 0) return kWave;  // (the any-tile-count path is bound by its serial tile
+                                                                             // loops: half waves 101.8 -> 120.9 us at 6x6 / 12 tiles)
   // Once the STATE of the batch no longer fits the Infinity Cache either (tens of millions of boards) a partial wave's short
   // pieces of every state row cost more than its shorter chunk wins: 4x4 at 64M boards 3.35 ms with half waves, 2.57 with full
   // ones (at 16M boards, 300 MB of state, half waves still win: 592 vs 722 us).
   if (state_bytes > (640ull << 20)) return kWave;
   if (const int64_t forced = g_small_bpw.load(std::memory_order_relaxed); forced == 16 || forced == 32 || forced == 64) return (int)forced;
+  // (Streams beyond 1 GiB - cfg3's learner re-encoding 8,388,608 gathered 4x4 boards: 1.6 GB - want the shorter chunk again:
+  // full waves 284 us, half waves 250, while at 2M / 4M boards full waves win 56 / 113 against 64 / 127:
+  // profiles/r04_learner_side_sweep.log)
+  const uint64_t limit = primary * n_boards > (1ull << 30) ? 7u * 1024u : 14u * 1024u;
   for (int bpw = kWave; bpw > 16; bpw >>= 1)
-    if (primary * (uint64_t)bpw <= 14u * 1024u) return bpw;
+    if (primary * (uint64_t)bpw <= limit) return bpw;
   return 16;
 #endif
 }
@@ -2310,7 +2345,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.lds_wave_bytes = a.lds_oh_off + align16(a.oh_boards * (uint32_t)(a.onehot_ch * C)) + TS_SMALL_LDS_PAD;
     const uint64_t out_per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, a.obs ? 12ull * C : a.obs_u8 ? 3ull * C : 4ull * C * a.onehot_ch,
-                                            (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7));
+                                            (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7), (uint64_t)d->n_boards);
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
     if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(false, (uint64_t)a.bpw * out_per_board);

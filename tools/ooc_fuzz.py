@@ -23,7 +23,9 @@ for S in range(1, 9):
     C = S * S
     for T in sorted({1, min(2, C), min(3, C), min(5, C), min(8, C), min(12, C)}):
         cases.append((S, T, min(max(0, C - 2 * T) // 3, 6)))
-for S, T in ((9, 4), (10, 17), (12, 8), (15, 32), (16, 40), (17, 3), (20, 33), (24, 30), (32, 64)):
+for S, T in ((9, 4), (10, 17), (12, 8), (15, 32), (16, 40), (17, 3), (20, 33), (24, 30), (32, 64),
+             # round 4: tiles dealt over 4 / 8 lanes (7x7, 8x8), 8 lanes up to 13x13, 32 lanes per board, one board per wave
+             (7, 20), (7, 40), (8, 20), (8, 28), (8, 40), (11, 6), (13, 16), (20, 4), (26, 100), (28, 8), (30, 16), (32, 4)):
     cases.append((S, T, S))
 bad = 0
 t0 = time.time()

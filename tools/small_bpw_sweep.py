@@ -24,7 +24,8 @@ def rate(env, act, reps=40, warm=50):
 
 HINTS = (-4, 0, 4, 8)
 print(f"   S    T    K oh   boards | policy | per boards-per-wave 64 / 32 / 16: us at launch_hint {HINTS}")
-for S, T, K, oh in ((4, 2, 2, 0), (5, 2, 3, 0), (5, 2, 3, 1), (6, 3, 4, 0), (6, 8, 4, 0), (7, 5, 6, 0), (8, 4, 8, 0), (8, 8, 8, 0), (8, 1, 10, 0)):
+SHAPES = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [(4, 2, 2, 0), (5, 2, 3, 0), (5, 2, 3, 1), (6, 3, 4, 0), (6, 8, 4, 0), (7, 5, 6, 0), (8, 4, 8, 0), (8, 8, 8, 0), (8, 1, 10, 0)]
+for S, T, K, oh in SHAPES:
     per = 12 * S * S + (4 * S * S * (1 + 2 * T) if oh else 0)
     n = (600_000_000 // per) // 256 * 256
     bps = bench.algorithmic_bytes_per_board_step(S, T, bool(oh), bool(oh))
