@@ -41,6 +41,10 @@ CONFIGS = {
     "s9t4": dict(size=9, tiles=4, obstacles=9, boards=1 << 19, onehot=False, reward=False),
     "s12t8": dict(size=12, tiles=8, obstacles=16, boards=1 << 18, onehot=False, reward=False),
     "s32t64": dict(size=32, tiles=64, obstacles=100, boards=1 << 15, onehot=False, reward=False),
+    # round 4's launch forms beyond the cache (tools/soak.py): quarter waves, one board per wave on 32 lanes
+    "s7t5": dict(size=7, tiles=5, obstacles=6, boards=1 << 20, onehot=False, reward=False),
+    "s8t4": dict(size=8, tiles=4, obstacles=8, boards=1 << 19, onehot=False, reward=False),
+    "s28t8": dict(size=28, tiles=8, obstacles=60, boards=1 << 16, onehot=False, reward=False),
 }
 
 
