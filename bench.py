@@ -184,6 +184,11 @@ def main():
                          "to profile exactly the launches a tuned run settled on)")
     ap.add_argument("--output-memory", choices=["torch", "contiguous"], default="contiguous",
                     help="VecTilerSliderEnv(output_memory=...): physically contiguous output buffers beyond the Infinity Cache, or torch's allocator")
+    ap.add_argument("--obs-candidates", type=int, default=None,
+                    help="VecTilerSliderEnv(obs_candidates=...): the fastest of up to k candidate observation buffers (environments "
+                         "with one-hot planes run at one of two speeds by where the observation buffer lies, even in physically "
+                         "contiguous memory; ~2 ms per candidate at construction).  Default: the class default (8 for such "
+                         "environments, else 0); 0 = the first allocation")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-halves-on-two-streams figure")
     ap.add_argument("--no-sibling", action="store_true", help="skip the out-of-cache sibling of a cache-resident config")
     ap.add_argument("--clock-warmup-ms", type=float, default=150.0,
@@ -232,7 +237,8 @@ def main():
     env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
                                    seed=LEVEL_SEED, multi_color=True, max_steps=2**30, board_offset=rank * n,
                                    device=device, auto_reset=True, with_reward=cfg["reward"],
-                                   with_onehot=cfg["onehot"], placement_trials=args.placement_trials, output_memory=args.output_memory)
+                                   with_onehot=cfg["onehot"], placement_trials=args.placement_trials, output_memory=args.output_memory,
+                                   obs_candidates=args.obs_candidates)
     if args.policy:
         env._dims.launch_hint, env._dims.emit_edges, env._dims.lines_lanes, env._dims.xcd_piece = (int(x) for x in args.policy.split(","))
     env.reset()
@@ -456,6 +462,7 @@ def main():
                        # construction-time choice among candidate allocations of the output buffers (outside the
                        # timed region; only for batches beyond the Infinity Cache): VecTilerSliderEnv docstring
                        "placement_trials": args.placement_trials, "placement": env.placement_report, "output_memory": args.output_memory,
+                       "obs_candidates": args.obs_candidates, "observation_placement": env.observation_placement_report,
                        "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges,
                                          "lines_lanes": env._dims.lines_lanes, "xcd_piece": env._dims.xcd_piece},
                        "parallelism": f"boards sharded over {world} GPU(s), no data-path collective",
@@ -623,13 +630,17 @@ def time_config(name, trials, steps, device, L, stream):
     # static launch policy, nothing measured at construction (placement_trials = 0): the same in every process;
     # torch_allocator: the same policy on buffers from torch's caching allocator (one of two speeds, by allocation);
     # torch_allocator_rated: + launch policy rated at construction on those buffers; tuned: + candidate buffers (opt-in)
-    for key, k, mem in (("first_allocation_contiguous_memory", 0, "contiguous"), ("torch_allocator", 0, "torch"),
-                        ("torch_allocator_rated", 1, "torch"), ("tuned", trials, "torch")):
+    # class_default: what VecTilerSliderEnv(...) does with no placement arguments - contiguous memory, static policy, and for
+    # environments with one-hot planes (two large streams: the observation buffer's place decides between two speeds) the fastest
+    # of up to 8 candidate observation buffers; first_allocation_contiguous_memory: the same with obs_candidates=0
+    for key, k, mem, cand in (("class_default", 0, "contiguous", None), ("first_allocation_contiguous_memory", 0, "contiguous", 0),
+                              ("torch_allocator", 0, "torch", 0), ("torch_allocator_rated", 1, "torch", 0), ("tuned", trials, "torch", 0)):
         if key == "tuned" and trials <= 1:
             continue
         env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"], seed=LEVEL_SEED,
                                        multi_color=True, max_steps=2**30, device=device, auto_reset=True, with_reward=cfg["reward"],
-                                       with_onehot=cfg["onehot"], placement_trials=k, output_memory=mem)
+                                       with_onehot=cfg["onehot"], placement_trials=k, output_memory=mem,
+                                       obs_candidates=cand)
         env.reset()
         for i in range(50):
             env.step_async(acts[i & 3])
@@ -644,7 +655,7 @@ def time_config(name, trials, steps, device, L, stream):
         out[key] = {"placement_trials": k, "output_memory": mem, "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s", "achieved": gbs,
                     "achieved_unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS,
                     "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges, "lines_lanes": env._dims.lines_lanes, "xcd_piece": env._dims.xcd_piece},
-                    "placement": env.placement_report}
+                    "placement": env.placement_report, "observation_placement": env.observation_placement_report}
         del env
         torch.cuda.empty_cache()
     rec = pmc_traffic(name, n)

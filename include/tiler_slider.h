@@ -103,7 +103,10 @@ typedef struct ts_dims {
   /* Launch policy of THIS call (speed only, never results; 0 everywhere = the library's own policy).  They matter for
    * launches whose outputs do not fit the 256 MiB Infinity Cache, where the best values depend on the shape and on where
    * the output buffers were allocated.  The library's policy assumes physically contiguous output
-   * buffers; VecTilerSliderEnv(placement_trials >= 1) rates a few combinations at construction for other memory. */
+   * buffers; VecTilerSliderEnv(placement_trials >= 1) rates a few combinations at construction for other memory.  (A launch
+   * that writes two large streams - observation and one-hot planes - runs at one of two speeds even then, by where the
+   * observation buffer lies: the shipped host code keeps the fastest of a few candidate buffers, VecTilerSliderEnv
+   * obs_candidates.) */
   int32_t launch_hint; /* -8 .. +8: resident blocks per CU relative to the policy.  Anything else: TS_ERR_DIMS.
                         * (The field was `reserved`, must-be-zero, before ABI v3.) */
   int32_t emit_edges;  /* ABI v4.  0 = policy; 1 + e (e = 0 .. 3): bit 0 / bit 1 of e = the first / last store instruction

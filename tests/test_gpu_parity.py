@@ -954,17 +954,24 @@ def test_placement_trials_leave_no_trace(torch_cuda, oracle):
         assert 1 <= rep["trials"] <= 3 and len(rep["us_per_step"]) == rep["trials"] and 0 <= rep["chosen"] < rep["trials"]
         assert rep["us_per_step"][rep["chosen"]] == min(rep["us_per_step"])
         assert tuned._dims.launch_hint == rep["launch_hint"][rep["chosen"]] and -8 <= tuned._dims.launch_hint <= 8
-        for t in ("_pos", "_step_count", "_done", "_flags", "_reward"):
-            assert torch.equal(getattr(plain, t), getattr(tuned, t)), t
-        assert int(tuned._obs.abs().sum()) == 0
-        assert torch.equal(plain.reset(), tuned.reset())
+        # obs_candidates: the fastest of a few candidate OBSERVATION buffers (both slots of the ring), static policy
+        picked = VecTilerSliderEnv.random(N, auto_reset=autoreset, obs_candidates=4, obs_buffers=2, **kw)
+        orep = picked.observation_placement_report
+        assert len(orep) == 2 and all(1 <= len(r["us_per_step"]) <= 4 and r["us_per_step"][r["chosen"]] == min(r["us_per_step"]) for r in orep)
+        assert picked.placement_report is None and (picked._dims.launch_hint, picked._dims.xcd_piece) == (0, 0)
+        for other in (tuned, picked):
+            for t in ("_pos", "_step_count", "_done", "_flags", "_reward"):
+                assert torch.equal(getattr(plain, t), getattr(other, t)), t
+            assert int(other._obs.abs().sum()) == 0 and int(other._obs_ring[1].abs().sum()) == 0
+        assert torch.equal(plain.reset(), tuned.reset()) and torch.equal(plain._obs, picked.reset())
         for step in range(9):
             act = torch.from_numpy(oracle.fill_actions(N, seed=8, step_index=step))
             o1, d1, i1 = plain.step(act)
-            o2, d2, i2 = tuned.step(act)
-            assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(i1["flags"], i2["flags"])
-            assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(plain.positions, tuned.positions)
-        del plain, tuned
+            for other in (tuned, picked):
+                o2, d2, i2 = other.step(act)
+                assert torch.equal(o1, o2) and torch.equal(d1, d2) and torch.equal(i1["flags"], i2["flags"])
+                assert torch.equal(i1["reward"], i2["reward"]) and torch.equal(plain.positions, other.positions)
+        del plain, tuned, picked
         torch.cuda.empty_cache()
 
 

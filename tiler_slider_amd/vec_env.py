@@ -75,7 +75,7 @@ class VecTilerSliderEnv:
     def __init__(self, size, blocked_locations=None, initial_locations=None, target_locations=None,
                  multi_color=False, max_steps=100, *, device=None, strict=False, auto_reset=False,
                  with_reward=False, with_onehot=False, with_valid_moves=False, obs_dtype="float32",
-                 host_mapped=False, obs_buffers=1, placement_trials=0, output_memory="contiguous"):
+                 host_mapped=False, obs_buffers=1, placement_trials=0, output_memory="contiguous", obs_candidates=None):
         """blocked/initial/target_locations: one list of (row, col) per board.
 
         strict      : raise the reference's RuntimeError when any board is stepped after done
@@ -100,6 +100,17 @@ class VecTilerSliderEnv:
                       process, so the step time is a property of the code: the library's launch policy is tuned on it
                       (cfg2 118 us, cfg4 107 us on every run; ordinary allocations give cfg2 112-134, cfg4 103-118).
                       Smaller outputs always come from torch's allocator.
+        obs_candidates : environments that write TWO large streams per step (observation + one-hot planes, beyond the Infinity
+                      Cache) run at one of two speeds even in physically contiguous memory - cfg2: 113 us or 119-120 us -
+                      decided by where the OBSERVATION buffer lies (crossing the buffers of a fast and a slow environment:
+                      profiles/r04_cross_probe.log; fast and slow regions of VRAM come in runs of several GiB:
+                      r04_period_probe.log; single-stream launches - no one-hot - show no classes: r04_class_probe.log).
+                      k > 1: the constructor allocates up to k candidate observation buffers (all alive, so that each lands
+                      elsewhere), rates each with eleven launches of the real step kernel at the library's static policy,
+                      keeps the fastest and frees the rest; it stops as soon as both classes have been seen and the current
+                      one is fast (about 2 ms and one observation buffer of transient memory per candidate; the launch
+                      policy is not touched, results never differ).  None (default): 8 for such two-stream environments,
+                      0 otherwise.  `observation_placement_report` holds the timings.
         placement_trials : opt-in measuring at construction, for buffers that are NOT contiguous (or to squeeze the last
                       per cent out of a given box).  0 (default): none - the library's static launch policy.  1: the
                       constructor rates a handful of launch policies (the per-call fields of ts_dims: resident blocks per
@@ -119,7 +130,7 @@ class VecTilerSliderEnv:
         target_locations = target_locations if target_locations is not None else [[] for _ in range(n)]
         blk, init, tgt = pack_levels(size, blocked_locations, initial_locations or [], target_locations)
         self._setup(size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
-                    with_onehot, with_valid_moves, obs_dtype, host_mapped, obs_buffers, placement_trials, output_memory)
+                    with_onehot, with_valid_moves, obs_dtype, host_mapped, obs_buffers, placement_trials, output_memory, obs_candidates)
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -131,7 +142,8 @@ class VecTilerSliderEnv:
         self._setup(size, blk, init, tgt, multi_color, max_steps, kw.pop("device", None), kw.pop("strict", False),
                     kw.pop("auto_reset", False), kw.pop("with_reward", False), kw.pop("with_onehot", False),
                     kw.pop("with_valid_moves", False), kw.pop("obs_dtype", "float32"), kw.pop("host_mapped", False),
-                    kw.pop("obs_buffers", 1), kw.pop("placement_trials", 0), kw.pop("output_memory", "contiguous"))
+                    kw.pop("obs_buffers", 1), kw.pop("placement_trials", 0), kw.pop("output_memory", "contiguous"),
+                    kw.pop("obs_candidates", None))
         if kw:
             raise TypeError(f"unexpected arguments {sorted(kw)}")
         if validate:
@@ -222,7 +234,7 @@ class VecTilerSliderEnv:
     # ------------------------------------------------------------------ setup
     def _setup(self, size, blk, init, tgt, multi_color, max_steps, device, strict, auto_reset, with_reward,
                with_onehot, with_valid_moves, obs_dtype="float32", host_mapped=False, obs_buffers=1, placement_trials=0,
-               output_memory="contiguous"):
+               output_memory="contiguous", obs_candidates=None):
         L = _cabi.lib()  # raises when the HIP library is missing: no fallback
         self._fns = {}
         self.device = _resolve_device(device)
@@ -280,7 +292,11 @@ class VecTilerSliderEnv:
             self._state.lines = _ptr(self._lines)
         self._mode = _cabi.MODE_AUTORESET if self.auto_reset else _cabi.MODE_STRICT
         self._bind_outputs()
-        self.placement_report = None
+        self.placement_report = self.observation_placement_report = None
+        if obs_candidates is None:  # two large output streams: the observation buffer's place decides between two speeds
+            obs_candidates = 8 if (self._onehot is not None and self._outputs_beyond_cache and not self.host_mapped) else 0
+        if int(obs_candidates) > 1:
+            self._choose_observation_buffers(int(obs_candidates))
         if int(placement_trials) >= 1:
             self._tune_placement(int(placement_trials))
         self.observation_shape = (self.size, self.size, 3)  # per board, environment.py:59
@@ -295,6 +311,67 @@ class VecTilerSliderEnv:
         self._obs_slot = 0
         self._obs = self._obs_ring[0]
         self._out = self._outs[0]
+
+    def _choose_observation_buffers(self, k):
+        """`obs_candidates=k`: per slot of the observation ring, the fastest of up to k candidate buffers (see the constructor)."""
+        if self.host_mapped or self.num_envs == 0 or not self._outputs_beyond_cache:
+            self.observation_placement_report = {"skipped": "outputs fit the Infinity Cache" if not self.host_mapped else "host-mapped"}
+            return
+        N, L = self.num_envs, _cabi.lib()
+        with torch.cuda.device(self.device):
+            free, _ = torch.cuda.mem_get_info()
+        k = max(1, min(k, int(free * 0.25 // max(self._obs_ring[0].numel() * self._obs_ring[0].element_size(), 1))))  # transient memory: a quarter of what is free
+        saved = (self._pos.clone(), self._step_count.clone(), self._done.clone(), self._flags.clone())
+        acts = self._empty(N, torch.uint8)
+        self._call("ts_fill_actions", N, C.c_uint64(0xAC710005), 0, 0, _ptr(acts))
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        report = []
+
+        def rate(out):
+            for i in range(11):
+                if i == 3:
+                    ev0.record()
+                _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(out), stream), "ts_step")
+            ev1.record()
+            ev1.synchronize()
+            return ev0.elapsed_time(ev1) * 1e3 / 8
+
+        original = list(self._obs_ring)
+        try:
+            with torch.cuda.device(self.device):
+                for _ in range(300):  # clocks up before the first rating (tens of ms of load; a cold first rating reads 3-4 % slow
+                    # and would pass for the slow class)
+                    _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(self._outs[0]), stream), "ts_step")
+                for slot in range(len(self._obs_ring)):
+                    cands, times = [self._obs_ring[slot]], []
+                    for c in range(k):
+                        if c:
+                            cands.append(self._big_zeros(tuple(cands[0].shape), cands[0].dtype))
+                        self._obs_ring[slot] = cands[c]
+                        self._bind_outputs()
+                        times.append(rate(self._outs[slot]))
+                        # both classes seen and this one is of the fast kind: stop looking
+                        if len(times) >= 2 and times[-1] <= min(times) * 1.01 and max(times) >= times[-1] * 1.035:
+                            break
+                    best = min(range(len(times)), key=times.__getitem__)
+                    self._obs_ring[slot] = cands[best]
+                    report.append({"us_per_step": [round(t, 2) for t in times], "chosen": best})
+                    del cands
+        except BaseException:
+            self._obs_ring = original
+            raise
+        finally:
+            for o in self._obs_ring:
+                o.zero_()
+            if self._onehot is not None:
+                self._onehot.zero_()
+            self._pos.copy_(saved[0]), self._step_count.copy_(saved[1]), self._done.copy_(saved[2]), self._flags.copy_(saved[3])
+            for t in (self._reward, self._valid, self._valid4):
+                if t is not None:
+                    t.zero_()
+            self._bind_outputs()
+        self.observation_placement_report = report
 
     # Beyond the Infinity Cache the step time depends on WHERE the large output buffers were allocated and, with that, on
     # the launch policy that suits them (resident blocks per CU, write-back edge stores, lanes per board): the same kernel

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round-4 profiles (GPU box): the default bench run, then rocprofv3 --kernel-trace --stats per config with the class defaults
 # (physically contiguous output buffers, static launch policy: every launch of the dominant kernel in the process is one the
-# bench line times), separate --pmc passes (WRITE_SIZE, FETCH_SIZE), cfg2 on torch's allocator in fresh processes (the two
-# speeds), three fresh processes of cfg2 / cfg4 (reproducibility), and the entry-point kernel traces.
+# bench line times - except cfg2's, whose constructor rates up to 8 candidate observation buffers with 11 launches each first),
+# separate --pmc passes (WRITE_SIZE, FETCH_SIZE), cfg2 with the first allocation and on torch's allocator in fresh processes (the
+# two speeds), three fresh processes of cfg2 / cfg4 (reproducibility), and the entry-point kernel traces.
 set -o pipefail
 OUT=gpurun_out/r04_prof
 mkdir -p $OUT
@@ -18,9 +19,11 @@ for spec in "cfg1:--config cfg1 --no-sibling" "cfg2:--config cfg2" "cfg4:--confi
   done
   echo "$name done"
 done
+# cfg2 with the first observation buffer the runtime hands out (obs_candidates=0): the slow class in a fresh process
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg2_first -- python3 bench.py --config cfg2 --obs-candidates 0 $COMMON > $OUT/bench_cfg2_first_profiled.json 2> $OUT/stats_cfg2_first.err || { tail -5 $OUT/stats_cfg2_first.err; exit 1; }
 # cfg2 on torch's caching allocator, four fresh processes under the profiler: whichever speeds they land on
 for k in 1 2 3 4; do
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg2_torch$k -- python3 bench.py --config cfg2 --output-memory torch $COMMON > $OUT/bench_cfg2_torch${k}_profiled.json 2> $OUT/stats_cfg2_torch$k.err || { tail -5 $OUT/stats_cfg2_torch$k.err; exit 1; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_cfg2_torch$k -- python3 bench.py --config cfg2 --output-memory torch --obs-candidates 0 $COMMON > $OUT/bench_cfg2_torch${k}_profiled.json 2> $OUT/stats_cfg2_torch$k.err || { tail -5 $OUT/stats_cfg2_torch$k.err; exit 1; }
 done
 echo "torch allocator done"
 # reproducibility: three fresh, unprofiled processes each
