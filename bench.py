@@ -269,8 +269,23 @@ def main():
             clock_warmup["steps"] += 64
         clock_warmup["ms"] = (time.perf_counter() - t_w) * 1e3
 
-    for i in range(args.warmup):
-        env.step_async(ring[i & 15])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def run_steps(k, graph=None):
+        """k step launches between two HIP events on the launch stream, then the synchronize of the contract."""
+        ev0.record()
+        if graph is not None:
+            graph.replay()
+        else:
+            for i in range(k):
+                env.step_async(ring[i & 15])
+        ev1.record()
+        torch.cuda.synchronize(device)
+
+    # the W warm-up steps run through the SAME host code as the timed region (events, launches, synchronize): executed for the
+    # first time, that path costs ~40 us more than the second time - 6 % of a 20-step window (profiles/r04_timed_region_probe.log)
+    if args.warmup > 0:
+        run_steps(args.warmup)
     graph = None
     if args.graph:
         torch.cuda.synchronize(device)
@@ -278,22 +293,11 @@ def main():
         with torch.cuda.graph(graph):
             for i in range(args.steps):
                 env.step_async(ring[i & 15])
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
     # timed region: barrier + synchronize, K steps, synchronize (clock stops when THIS rank's K
     # steps have finished) + barrier; the slowest rank's time is taken below (MAX over ranks)
     barrier()
     t0 = time.perf_counter()
-    ev0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for i in range(args.steps):
-            env.step_async(ring[i & 15])
-    ev1.record()
-    while not ev1.query():  # busy-wait for the last step (a blocking wait's wake-up costs tens of us: 4 % of a 20-step window) ...
-        pass
-    torch.cuda.synchronize(device)  # ... then the synchronize of the contract, which returns at once
+    run_steps(args.steps, graph)
     wall = time.perf_counter() - t0
     barrier()
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
