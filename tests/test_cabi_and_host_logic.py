@@ -303,3 +303,18 @@ def test_vgpr_allocation_padding_rule():
     out, n = _cabi.pad_vgpr_allocations(asm)
     assert n == 3 and ".amdhsa_next_free_vgpr 65" in out
     assert [_vgpr_guard.waves_per_simd(v) for v in (32, 64, 65, 96, 97, 128, 129)] == [8, 8, 7, 5, 4, 4, 3]
+
+
+def test_bench_workloads_and_algorithmic_bytes():
+    """bench.py's configs are BASELINE.json's single-GPU configs with SURVEY.md section 8(d)'s algorithmic bytes per board-step."""
+    import json
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert "1,048,576 concurrent 4×4 boards" in base["configs"][1] and "262,144 concurrent 15×15" in base["configs"][4]
+    want = {"cfg1": (4, 2, 2, 1 << 20, 212), "cfg2": (5, 2, 3, 1 << 20, 826), "cfg4": (15, 32, 24, 1 << 18, 2840)}
+    for name, (S, T, K, n, bps) in want.items():
+        c = bench.CONFIGS[name]
+        assert (c["size"], c["tiles"], c["obstacles"], c["boards"]) == (S, T, K, n)
+        assert bench.algorithmic_bytes_per_board_step(S, T, c["onehot"], c["reward"]) == bps
+    assert bench.algorithmic_bytes_per_board_step(5, 2, False, False) == 322   # cfg2 without its extensions
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.INFINITY_CACHE_BYTES == 256 << 20

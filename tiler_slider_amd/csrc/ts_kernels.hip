@@ -1877,10 +1877,44 @@ __device__ __noinline__ void mt_level_general(uint32_t seed, uint32_t *blk, void
   mt_store_level([&](int i) -> int { return perm[i]; }, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
 }
 
+// Boards above 18x18 (more than 623 draws: a 32x32 board takes ~1,400): the 624-word state in scratch memory, twisted ONE WORD AT
+// A TIME and in LOCK-STEP - all 64 seeds of a wave draw output k in the same iteration (a rejected draw just does not advance
+// that lane's shuffle), so every access to the state is at a uniform index: 256 contiguous bytes per wave.  (Round 3's kernel -
+// mt_level_general above, now only the hand-over target of the streamed forms - twists whole blocks and then reads word `pos`
+// per lane.)  Word i of the twisted state depends on words i, i + 1 and i + 397 (mod 624) as they stand when a sequential
+// block twist reaches i - old above i, new below - which is exactly their content here.
 __global__ __launch_bounds__(64) void k_generate_mt19937_general(uint32_t *blk, void *init_v, void *tgt_v, const uint32_t *seeds, int64_t N,
                                                                   int S, int T, int Tt, int K, int wide) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n < N) mt_level_general(seeds[n], blk, init_v, tgt_v, N, n, S * S, T, Tt, K, wide);
+  const bool live = n < N;
+  const int C = S * S;
+  uint32_t mt[kMtN];
+  uint16_t perm[TS_MAX_SIZE * TS_MAX_SIZE];
+  uint32_t x = seeds[live ? n : N - 1];
+  for (int i = 0; i < kMtN; ++i) {
+    mt[i] = x;
+    x = mt_seed_step(x, (uint32_t)(i + 1));
+  }
+  for (int i = 0; i < C; ++i) perm[i] = (uint16_t)i;
+  int i = C - 1, idx = 0;
+  for (;;) {
+    const bool active = live && i >= 1;
+    if (__ballot(active) == 0) break;  // uniform
+    const int i1 = idx + 1 == kMtN ? 0 : idx + 1, im = idx + kMtM >= kMtN ? idx + kMtM - kMtN : idx + kMtM;
+    const uint32_t u = mt[im] ^ mt_twist(mt[idx], mt[i1]);
+    mt[idx] = u;
+    idx = i1;
+    if (active) {
+      const uint32_t j = mt_temper(u) & mask_for((uint32_t)i);
+      if (j <= (uint32_t)i) {
+        const uint16_t t = perm[i];
+        perm[i] = perm[j];
+        perm[j] = t;
+        --i;
+      }
+    }
+  }
+  if (live) mt_store_level([&](int c) -> int { return perm[c]; }, blk, init_v, tgt_v, N, n, C, T, Tt, K, wide);
 }
 
 // The streamed forms.  All 64 seeds of a wave draw output k of their generators in the same iteration (a lane whose draw is

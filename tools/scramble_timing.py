@@ -7,7 +7,7 @@ from tiler_slider_amd import VecTilerSliderEnv, _cabi
 
 L = _cabi.lib()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for S, T, K, n in ((4, 2, 2, 1 << 20), (5, 2, 3, 1 << 20), (8, 20, 10, 1 << 19), (15, 32, 24, 1 << 18), (15, 32, 24, 1 << 20), (32, 64, 100, 1 << 15)):
+for S, T, K, n in ((4, 2, 2, 1 << 20), (5, 2, 3, 1 << 20), (8, 20, 10, 1 << 19), (15, 32, 24, 1 << 18), (15, 32, 24, 1 << 20), (18, 8, 20, 1 << 18), (20, 8, 20, 1 << 17), (24, 8, 20, 1 << 16), (32, 64, 100, 1 << 15), (32, 64, 100, 1 << 18)):
     seeds = torch.arange(n, dtype=torch.int64).to(torch.int32).cuda()
     env = VecTilerSliderEnv.from_seeds(torch.arange(64), size=S, num_tiles=T, num_obstacles=K, multi_color=True)  # warm
     dt = torch.uint8 if S <= 16 else torch.int16
