@@ -77,6 +77,9 @@
 #ifndef TS_ABLATE  // development only (tools/variant_bench.py): 1 = skip the observation stores, 2 = k_small: only those
 #define TS_ABLATE 0
 #endif
+#ifndef TS_TWO_STREAM  // development only: k_small launches with observation AND one-hot planes.  Bit 0: planes before the
+#define TS_TWO_STREAM 0  // observation; bit 1 / 2: write-back instead of nontemporal observation / plane stores; bit 3: vmcnt(0) between
+#endif
 #ifndef TS_MAX_TFIX  // largest tile count with a register-resident instantiation of k_small (4, 6 or 8)
 #define TS_MAX_TFIX 8
 #endif
@@ -698,7 +701,9 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   // ---- observation (state.py:188-211) through the LDS byte image ----
   // kObsBoards boards per pass: all 64 up to 5x5; two passes of 32 from 6x6 on, which halves
   // the image (the dominant LDS user there) and doubles the resident waves.
-  if (a.obs || a.obs_u8) {
+  constexpr bool kObsNT = NT && !(EXTRAS && (TS_TWO_STREAM & 2));
+  constexpr bool kPlanesNT = NT && !(TS_TWO_STREAM & 4);
+  auto emit_observation = [&]() {
     for (int c0 = 0; c0 < nb; c0 += kObsBoards) {
       if (c0) wave_sync();  // the previous pass has been read out
       for (int off = lane * 16; off < kImg; off += kWave * 16) *reinterpret_cast<uint4 *>(img + off) = make_uint4(0, 0, 0, 0);
@@ -719,10 +724,13 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
-      if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
+      if (a.obs) emit_bytes_as_f32<kObsNT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
       if (a.obs_u8) emit_bytes_raw<16, NT>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
     }
-  }
+  };
+  const bool planes_first = EXTRAS && (TS_TWO_STREAM & 1) && a.onehot && a.oh_boards > 0;
+  if ((a.obs || a.obs_u8) && !planes_first) emit_observation();
+  if (EXTRAS && (TS_TWO_STREAM & 8) && a.onehot) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): a wave's observation has left before its planes
 
   // ---- build-defined one-hot planes [board][Ch][S][S] ----
   if (EXTRAS && a.onehot && a.oh_boards > 0) {
@@ -755,10 +763,11 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       // a wave's first chunk starts on a 128-byte line (n0 is a multiple of 32 boards); later chunks do so only when
       // 4 * D * nbc is a multiple of 128 - not for odd board sizes in multi-colour mode with fewer than 32 boards per chunk
       if (((nbc * D) & 31) == 0)
-        emit_bytes_as_f32<NT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
+        emit_bytes_as_f32<kPlanesNT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
       else
-        emit_bytes_as_f32<NT, true>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
+        emit_bytes_as_f32<kPlanesNT, true>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
     }
+    if (planes_first && (a.obs || a.obs_u8)) emit_observation();
   } else if (EXTRAS && a.onehot) {
     // Fallback for very many planes (one board's image above the LDS budget): every output
     // float is evaluated from the staged cells.

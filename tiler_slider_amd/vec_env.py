@@ -108,8 +108,9 @@ class VecTilerSliderEnv:
                       k > 1: the constructor allocates up to k candidate observation buffers (all alive, so that each lands
                       elsewhere), rates each with eleven launches of the real step kernel at the library's static policy,
                       keeps the fastest and frees the rest; it stops as soon as both classes have been seen and the current
-                      one is fast (about 2 ms and one observation buffer of transient memory per candidate; the launch
-                      policy is not touched, results never differ).  None (default): 8 for such two-stream environments,
+                      one is fast (about 2 ms and one observation buffer of transient memory per candidate, at most a quarter of the free memory; the launch
+                      policy is not touched, results never differ).  None (default): 16 for such two-stream environments (the fast class turned up within six candidates in 40 of 40
+                      constructions between other allocations of 0-6 GiB: profiles/r04_obs_candidates_robustness.log),
                       0 otherwise.  `observation_placement_report` holds the timings.
         placement_trials : opt-in measuring at construction, for buffers that are NOT contiguous (or to squeeze the last
                       per cent out of a given box).  0 (default): none - the library's static launch policy.  1: the
@@ -294,7 +295,7 @@ class VecTilerSliderEnv:
         self._bind_outputs()
         self.placement_report = self.observation_placement_report = None
         if obs_candidates is None:  # two large output streams: the observation buffer's place decides between two speeds
-            obs_candidates = 8 if (self._onehot is not None and self._outputs_beyond_cache and not self.host_mapped) else 0
+            obs_candidates = 16 if (self._onehot is not None and self._outputs_beyond_cache and not self.host_mapped) else 0
         if int(obs_candidates) > 1:
             self._choose_observation_buffers(int(obs_candidates))
         if int(placement_trials) >= 1:
@@ -320,6 +321,9 @@ class VecTilerSliderEnv:
         N, L = self.num_envs, _cabi.lib()
         with torch.cuda.device(self.device):
             free, _ = torch.cuda.mem_get_info()
+        # (Keeping the candidates apart with unused allocations in between - 1.2 GiB, or 1 / 2 / 4 / 8 GiB in turn - finds the
+        # fast class LESS often than candidates that follow each other directly: 16 and 19 of 20 constructions against 20 of
+        # 20, profiles/r04_obs_candidates_robustness.log.)
         k = max(1, min(k, int(free * 0.25 // max(self._obs_ring[0].numel() * self._obs_ring[0].element_size(), 1))))  # transient memory: a quarter of what is free
         saved = (self._pos.clone(), self._step_count.clone(), self._done.clone(), self._flags.clone())
         acts = self._empty(N, torch.uint8)

@@ -64,7 +64,7 @@ def run(a):
     for _ in range(a.placement + 1):  # the step time depends on where the buffers landed (tools/placement_study.py)
         env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
                                        seed=bench.LEVEL_SEED, multi_color=True, max_steps=2**30, device=dev,
-                                       auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"], placement_trials=0)
+                                       auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"], placement_trials=0, obs_candidates=0)
         keep.append(env)
     env.reset()
     env._dims.launch_hint, env._dims.xcd_piece, env._dims.emit_edges = a.hint, a.piece, a.edges
@@ -99,6 +99,10 @@ def run(a):
                               C.POINTER(_cabi.StepOut), C.c_void_p]
         L.ts_step.restype = C.c_int32
         libs[name] = L
+        for kv in (a.tuning.split(",") if a.tuning else []):  # ts_tuning knobs (include/tiler_slider.h), e.g. 8=16: k_small quarter waves
+            key, _, val = kv.partition("=")
+            L.ts_tuning.argtypes, L.ts_tuning.restype = [C.c_int32, C.c_int64], C.c_int64
+            L.ts_tuning(int(key), int(val))
 
     def step(L, i):
         rc = L.ts_step(C.byref(env._dims), C.byref(env._state), ring[i & 15].data_ptr(), env._mode, C.byref(env._out), stream)
@@ -163,6 +167,7 @@ if __name__ == "__main__":
     r.add_argument("--piece", type=int, default=0, help="ts_dims.xcd_piece for every variant")
     r.add_argument("--edges", type=int, default=0, help="ts_dims.emit_edges for every variant")
     r.add_argument("--tag", default="")
+    r.add_argument("--tuning", help="ts_tuning settings for every variant: key=value,key=value")
     r.add_argument("--placement", type=int, default=0, help="use the K-th allocation of the environment")
     r.add_argument("--pick", choices=["slowest", "fastest"], help="with --placement K: rate the K+1 allocations, use that one")
     args = ap.parse_args()
