@@ -77,8 +77,8 @@
 #ifndef TS_ABLATE  // development only (tools/variant_bench.py): 1 = skip the observation stores, 2 = k_small: only those
 #define TS_ABLATE 0
 #endif
-#ifndef TS_TWO_STREAM  // development only: k_small launches with observation AND one-hot planes.  Bit 0: planes before the
-#define TS_TWO_STREAM 0  // observation; bit 1 / 2: write-back instead of nontemporal observation / plane stores; bit 3: vmcnt(0) between
+#ifndef TS_PLANES_FIRST  // k_small launches with observation AND one-hot planes: -1 = by shape (k_small), 0 / 1 = observation / planes first
+#define TS_PLANES_FIRST -1
 #endif
 #ifndef TS_MAX_TFIX  // largest tile count with a register-resident instantiation of k_small (4, 6 or 8)
 #define TS_MAX_TFIX 8
@@ -701,8 +701,6 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   // ---- observation (state.py:188-211) through the LDS byte image ----
   // kObsBoards boards per pass: all 64 up to 5x5; two passes of 32 from 6x6 on, which halves
   // the image (the dominant LDS user there) and doubles the resident waves.
-  constexpr bool kObsNT = NT && !(EXTRAS && (TS_TWO_STREAM & 2));
-  constexpr bool kPlanesNT = NT && !(TS_TWO_STREAM & 4);
   auto emit_observation = [&]() {
     for (int c0 = 0; c0 < nb; c0 += kObsBoards) {
       if (c0) wave_sync();  // the previous pass has been read out
@@ -724,13 +722,19 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
-      if (a.obs) emit_bytes_as_f32<kObsNT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
+      if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
       if (a.obs_u8) emit_bytes_raw<16, NT>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
     }
   };
-  const bool planes_first = EXTRAS && (TS_TWO_STREAM & 1) && a.onehot && a.oh_boards > 0;
+  // Launches that write TWO streams beyond the Infinity Cache: a wave of 5x5 boards writes its planes first.  Measured, not
+  // derived (profiles/r04_planes_first.log, r04_two_stream_variants*.log; same buffers, both orders): cfg2 113.5 -> 109.4 us
+  // (0.955 -> 0.99 of 8 TB/s) on observation buffers of the fast class and 119.0 -> 118.2 on the slow one, 5x5 with three tiles
+  // 140.4 -> 135.4, 2M boards 229.1 -> 224.3; 4x4, 6x6, 7x7 lose 0.2 - 1.5 %, 8x8 goes either way by 1 - 2 %, so they keep the
+  // observation first.  (Also tried there: a vmcnt(0) wait between the two streams - slower on fast buffers; write-back stores
+  // for either stream - 119 -> 147 us.)
+  constexpr bool kPlanesFirstShape = TS_PLANES_FIRST < 0 ? (NT && S == 5) : TS_PLANES_FIRST != 0;
+  const bool planes_first = EXTRAS && kPlanesFirstShape && a.onehot && a.oh_boards > 0;
   if ((a.obs || a.obs_u8) && !planes_first) emit_observation();
-  if (EXTRAS && (TS_TWO_STREAM & 8) && a.onehot) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): a wave's observation has left before its planes
 
   // ---- build-defined one-hot planes [board][Ch][S][S] ----
   if (EXTRAS && a.onehot && a.oh_boards > 0) {
@@ -763,9 +767,9 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       // a wave's first chunk starts on a 128-byte line (n0 is a multiple of 32 boards); later chunks do so only when
       // 4 * D * nbc is a multiple of 128 - not for odd board sizes in multi-colour mode with fewer than 32 boards per chunk
       if (((nbc * D) & 31) == 0)
-        emit_bytes_as_f32<kPlanesNT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
+        emit_bytes_as_f32<NT>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
       else
-        emit_bytes_as_f32<kPlanesNT, true>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
+        emit_bytes_as_f32<NT, true>(oimg, a.onehot + (n0 + c0) * (int64_t)D, nbb * D, lane, a.emit_edges);
     }
     if (planes_first && (a.obs || a.obs_u8)) emit_observation();
   } else if (EXTRAS && a.onehot) {

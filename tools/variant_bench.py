@@ -54,7 +54,7 @@ def run(a):
     names = [n for n in manifest if not a.only or n in a.only.split(",")]
     if a.shape:
         S_, T_, K_, N_ = (int(x) for x in a.shape.split(","))
-        bench.CONFIGS[a.config] = dict(size=S_, tiles=T_, obstacles=K_, boards=N_, onehot=False, reward=False)
+        bench.CONFIGS[a.config] = dict(size=S_, tiles=T_, obstacles=K_, boards=N_, onehot=a.onehot, reward=a.onehot)
     cfg = dict(bench.CONFIGS[a.config])
     if a.boards:
         cfg["boards"] = a.boards
@@ -64,7 +64,7 @@ def run(a):
     for _ in range(a.placement + 1):  # the step time depends on where the buffers landed (tools/placement_study.py)
         env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"],
                                        seed=bench.LEVEL_SEED, multi_color=True, max_steps=2**30, device=dev,
-                                       auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"], placement_trials=0, obs_candidates=0)
+                                       auto_reset=True, with_reward=cfg["reward"], with_onehot=cfg["onehot"], placement_trials=0, obs_candidates=a.obs_candidates)
         keep.append(env)
     env.reset()
     env._dims.launch_hint, env._dims.xcd_piece, env._dims.emit_edges = a.hint, a.piece, a.edges
@@ -167,6 +167,8 @@ if __name__ == "__main__":
     r.add_argument("--piece", type=int, default=0, help="ts_dims.xcd_piece for every variant")
     r.add_argument("--edges", type=int, default=0, help="ts_dims.emit_edges for every variant")
     r.add_argument("--tag", default="")
+    r.add_argument("--obs-candidates", type=int, default=0, help="VecTilerSliderEnv(obs_candidates=...)")
+    r.add_argument("--onehot", action="store_true", help="with --shape: one-hot planes and reward too")
     r.add_argument("--tuning", help="ts_tuning settings for every variant: key=value,key=value")
     r.add_argument("--placement", type=int, default=0, help="use the K-th allocation of the environment")
     r.add_argument("--pick", choices=["slowest", "fastest"], help="with --placement K: rate the K+1 allocations, use that one")
