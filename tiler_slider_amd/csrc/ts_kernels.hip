@@ -731,7 +731,8 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
   // (0.955 -> 0.99 of 8 TB/s) on observation buffers of the fast class and 119.0 -> 118.2 on the slow one, 5x5 with three tiles
   // 140.4 -> 135.4, 2M boards 229.1 -> 224.3; 4x4, 6x6, 7x7 lose 0.2 - 1.5 %, 8x8 goes either way by 1 - 2 %, so they keep the
   // observation first.  (Also tried there: a vmcnt(0) wait between the two streams - slower on fast buffers; write-back stores
-  // for either stream - 119 -> 147 us.)
+  // for either stream - 119 -> 147 us.  The narrow state stores - cells, counters, flags - belong BEFORE the big streams: behind
+  // them cfg2 109.0 -> 112.3 us, cfg4 108.3 -> 117.6, 8x8 with four tiles 71.3 -> 77.1: profiles/r04_state_stores_last.log.)
   constexpr bool kPlanesFirstShape = TS_PLANES_FIRST < 0 ? (NT && S == 5) : TS_PLANES_FIRST != 0;
   const bool planes_first = EXTRAS && kPlanesFirstShape && a.onehot && a.oh_boards > 0;
   if ((a.obs || a.obs_u8) && !planes_first) emit_observation();

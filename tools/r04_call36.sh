@@ -1,0 +1,13 @@
+set -e
+mkdir -p gpurun_out
+L=gpurun_out/r04_state_stores_last.log
+: > $L
+echo "== cfg2 (16 candidates)" >> $L
+timeout -k 10 300 python tools/variant_bench.py run --config cfg2 --rounds 6 --steps 100 --obs-candidates 16 >> $L 2>&1
+echo "== cfg4" >> $L
+timeout -k 10 300 python tools/variant_bench.py run --config cfg4 --rounds 6 --steps 100 >> $L 2>&1
+for shape in 4,2,2,4194304 8,4,8,650000 6,3,4,1048576 12,8,16,400000 14,20,20,300000 24,30,60,100000 32,32,100,60000 9,4,9,600000; do
+  echo "== $shape" >> $L
+  timeout -k 10 300 python tools/variant_bench.py run --config cfg1 --shape $shape --rounds 6 --steps 60 >> $L 2>&1
+done
+grep -v "amdgpu.ids\|rounds x" $L

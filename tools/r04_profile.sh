@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 profiles (GPU box): the default bench run, then rocprofv3 --kernel-trace --stats per config with the class defaults
 # (physically contiguous output buffers, static launch policy: every launch of the dominant kernel in the process is one the
-# bench line times - except cfg2's, whose constructor rates up to 8 candidate observation buffers with 11 launches each first),
+# bench line times - except cfg2's, whose constructor rates up to 16 candidate observation buffers with 11 launches each first),
 # separate --pmc passes (WRITE_SIZE, FETCH_SIZE), cfg2 with the first allocation and on torch's allocator in fresh processes (the
 # two speeds), three fresh processes of cfg2 / cfg4 (reproducibility), and the entry-point kernel traces.
 set -o pipefail
