@@ -636,7 +636,7 @@ def time_config(name, trials, steps, device, L, stream):
     # torch_allocator_rated: + launch policy rated at construction on those buffers; tuned: + candidate buffers (opt-in)
     # class_default: what VecTilerSliderEnv(...) does with no placement arguments - contiguous memory, static policy, and for
     # environments with one-hot planes (two large streams: the observation buffer's place decides between two speeds) the fastest
-    # of up to 8 candidate observation buffers; first_allocation_contiguous_memory: the same with obs_candidates=0
+    # of up to 16 candidate observation buffers; first_allocation_contiguous_memory: the same with obs_candidates=0
     for key, k, mem, cand in (("class_default", 0, "contiguous", None), ("first_allocation_contiguous_memory", 0, "contiguous", 0),
                               ("torch_allocator", 0, "torch", 0), ("torch_allocator_rated", 1, "torch", 0), ("tuned", trials, "torch", 0)):
         if key == "tuned" and trials <= 1:

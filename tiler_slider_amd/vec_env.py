@@ -101,17 +101,18 @@ class VecTilerSliderEnv:
                       (cfg2 118 us, cfg4 107 us on every run; ordinary allocations give cfg2 112-134, cfg4 103-118).
                       Smaller outputs always come from torch's allocator.
         obs_candidates : environments that write TWO large streams per step (observation + one-hot planes, beyond the Infinity
-                      Cache) run at one of two speeds even in physically contiguous memory - cfg2: 113 us or 119-120 us -
+                      Cache) run at one of two speeds even in physically contiguous memory - cfg2: 109 us or 118-119 us -
                       decided by where the OBSERVATION buffer lies (crossing the buffers of a fast and a slow environment:
                       profiles/r04_cross_probe.log; fast and slow regions of VRAM come in runs of several GiB:
                       r04_period_probe.log; single-stream launches - no one-hot - show no classes: r04_class_probe.log).
                       k > 1: the constructor allocates up to k candidate observation buffers (all alive, so that each lands
                       elsewhere), rates each with eleven launches of the real step kernel at the library's static policy,
-                      keeps the fastest and frees the rest; it stops as soon as both classes have been seen and the current
-                      one is fast (about 2 ms and one observation buffer of transient memory per candidate, at most a quarter of the free memory; the launch
-                      policy is not touched, results never differ).  None (default): 16 for such two-stream environments (the fast class turned up within six candidates in 40 of 40
-                      constructions between other allocations of 0-6 GiB: profiles/r04_obs_candidates_robustness.log),
-                      0 otherwise.  `observation_placement_report` holds the timings.
+                      keeps the fastest and frees the rest; it stops as soon as both classes have been seen (about 2 ms and
+                      one observation buffer of transient memory per candidate, at most a quarter of the free memory; the
+                      launch policy is not touched, results never differ).  None (default): 16 for such two-stream
+                      environments (the fast class turned up within six candidates in 40 of 40 constructions between other
+                      allocations of 0-6 GiB on one box, in none of 16 on another: r04_obs_candidates_robustness.log), 0
+                      otherwise.  `observation_placement_report` holds the timings.
         placement_trials : opt-in measuring at construction, for buffers that are NOT contiguous (or to squeeze the last
                       per cent out of a given box).  0 (default): none - the library's static launch policy.  1: the
                       constructor rates a handful of launch policies (the per-call fields of ts_dims: resident blocks per
@@ -355,8 +356,8 @@ class VecTilerSliderEnv:
                         self._obs_ring[slot] = cands[c]
                         self._bind_outputs()
                         times.append(rate(self._outs[slot]))
-                        # both classes seen and this one is of the fast kind: stop looking
-                        if len(times) >= 2 and times[-1] <= min(times) * 1.01 and max(times) >= times[-1] * 1.035:
+                        # both classes seen: the fastest so far is of the fast kind, stop looking
+                        if len(times) >= 2 and max(times) >= min(times) * 1.035:
                             break
                     best = min(range(len(times)), key=times.__getitem__)
                     self._obs_ring[slot] = cands[best]
