@@ -175,6 +175,7 @@ struct KArgs {
   uint32_t oh_boards;   // one-hot byte image: boards per chunk (0 = evaluate per float)
   uint32_t lds_oh_off;  // offset of that image inside the wave's carve
   uint32_t bpw;         // boards per wave (k_small: 64, k_lines: 4; fewer beyond the Infinity Cache)
+  uint32_t cached_every;  // k_small beyond the cache: every N-th wave writes its float32 observation with the cached stores (0 = none)
   uint32_t xcd_piece;   // block -> board-range mapping (xcd_contiguous_block): 0 = one contiguous eighth per XCD, P = pieces of P blocks
   uint32_t emit_edges;  // out-of-cache launches: bit 0 / 1 = first / last store instruction of a wave's chunk as write-back stores
   uint8_t *valid4;      // legality mask as the reference's shape: uint8 [N][4], 0 / 1 per move
@@ -722,7 +723,12 @@ __global__ TS_SMALL_BOUNDS void k_small(const KArgs a) {
       }
       wave_sync();
       const int nbb = (nb - c0) < kObsBoards ? (nb - c0) : kObsBoards;
-      if (a.obs) emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
+      if (a.obs) {
+        if (NT && a.cached_every && (uint32_t)(n0 / bpw) % a.cached_every == 0)  // wave-uniform (cached_every_policy)
+          emit_bytes_as_f32<false, true>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
+        else
+          emit_bytes_as_f32<NT>(img, a.obs + (n0 + c0) * (3 * C), nbb * 3 * C, lane, a.emit_edges);
+      }
       if (a.obs_u8) emit_bytes_raw<16, NT>(img, a.obs_u8 + (n0 + c0) * (3 * C), nbb * 3 * C, lane);
     }
   };
@@ -1278,7 +1284,12 @@ __global__ __launch_bounds__(256, (S == 8 && TPL <= 7 && !EXTRAS ? 8 : 1)) void 
     }
     wave_sync();
     // (unrolled by 4: eight conversions in flight cost 16 more VGPRs than this kernel's eight waves per SIMD leave)
-    if (a.obs) emit_bytes_as_f32<NT, !kChunkOnLine, 4>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+    if (a.obs) {
+      if (NT && a.cached_every && (uint32_t)(n0 / BPW) % a.cached_every == 0)  // wave-uniform (cached_every_policy)
+        emit_bytes_as_f32<false, true, 4>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+      else
+        emit_bytes_as_f32<NT, !kChunkOnLine, 4>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+    }
     if (a.obs_u8) emit_bytes_raw<kU8Vec, NT>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 
@@ -1641,7 +1652,12 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
       }
     }
     wave_sync();
-    if (a.obs) emit_bytes_as_f32<NT, true>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+    if (a.obs) {
+      if (NT && a.cached_every && (uint32_t)(n0 / bpw) % a.cached_every == 0)  // wave-uniform (cached_every_policy)
+        emit_bytes_as_f32<false, true>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+      else
+        emit_bytes_as_f32<NT, true>(img, a.obs + n0 * (int64_t)(3 * C), nb * 3 * C, lane, a.emit_edges);
+    }
     if (a.obs_u8) emit_bytes_raw<4, NT>(img, a.obs_u8 + n0 * (int64_t)(3 * C), nb * 3 * C, lane);
   }
 
@@ -2016,6 +2032,7 @@ std::atomic<int64_t> g_lines_lanes{0};  // ts_tuning(TS_TUNE_LINES_LANES): 0 = b
 std::atomic<int64_t> g_lines_bpw{0};    // ts_tuning(TS_TUNE_LINES_BPW): 0 = policy, else boards per wave of k_lines (the other lanes idle)
 std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): INT64_MAX = policy, 0 = eighths, P = pieces of P blocks (out-of-cache launches)
 std::atomic<int64_t> g_mt_window{kMtLongWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
+std::atomic<int64_t> g_cached_every{0};  // ts_tuning(TS_TUNE_CACHED_EVERY): 0 = policy, 1 = never, N >= 2 = every N-th wave of every k_small launch beyond the cache
 std::atomic<int64_t> g_small_bpw{0};  // ts_tuning(TS_TUNE_SMALL_BPW): 0 = policy, 16 / 32 / 64 = boards per wave of k_small's register forms beyond the cache
 std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
@@ -2247,6 +2264,29 @@ uint32_t piece_policy(bool lines_kernel, uint64_t chunk) {
 #endif
 }
 
+// A sprinkle of cached stores in a nontemporal stream (round 4).  Beyond the Infinity Cache every wave streams its chunk out with
+// nontemporal stores; when every 16th wave of a k_small launch uses the cached (agent-scope) stores instead - 6 % of the bytes,
+// a set of lines that fits the cache many times over and is rewritten in place by every step - batches of 270 .. 800 MB of
+// observation run 5 - 8 % faster at 6x6, 2 - 4 % at 5x5 and 3x3, 0.5 - 2.5 % at 8x8, and within 0.5 % at 4x4 and 7x7
+// (profiles/r04_cached_every_nth_wave*.log; every 8th wave gains a little more at 6x6 and loses 5 - 10 % elsewhere from 700 MB on;
+// every 2nd / 4th wave loses up to 30 % from 400 MB on: a quarter of the stream no longer stays resident).  From about 1 GB on
+// any such share hurts (4x4 at 1 GB: +3 .. 15 %), two-stream launches are at their ceiling already, and the kernels that deal a
+// board over several lanes go either way (cfg4 109 -> 139 us, 12x12 -4 %): those stay all-nontemporal; so do 1x1 and 2x2 boards
+// (2x2 with reward and legality mask at 8M boards: 91 -> 118 us; r04_cached_every_validation.log).
+uint32_t cached_every_policy(int S, uint64_t output_bytes, bool two_streams) {
+  const int64_t forced = g_cached_every.load(std::memory_order_relaxed);
+  if (forced == 1) return 0u;
+  if (forced >= 2 && forced <= 0x7fffffff) return (uint32_t)forced;
+  if (two_streams || output_bytes > (768ull << 20)) return 0u;
+  if (S >= 3 && S <= 8) return 16u;
+  // Boards above 16x16 (k_lines, 16-bit cells; r04_cached_every_wide_boards.log, thirteen shapes from 17x17 to 32x32): every 16th
+  // wave up to 512 MiB (-0.3 .. -8 %; 32x32 with 32 tiles 74.7 -> 68.8 us, 24x24 with 4 tiles 72.8 -> 66.8), every 32nd up to 768
+  // MiB (-0.2 .. -4.8 %, one shape +1.3 %; every 16th there: +6 % at 20x20 with 10 tiles).  9x9 .. 16x16 go either way (cfg4 +1.5 %
+  // even with every 32nd wave, 11x11 .. 13x13 -2.5 %): all-nontemporal.
+  if (S > 16) return output_bytes <= (512ull << 20) ? 16u : 32u;
+  return 0u;
+}
+
 // Boards per wave of k_small.  Beyond the Infinity Cache the register-path kernels run PARTIAL waves - 32 or 16 boards, the
 // upper lanes idle: the transition arithmetic is a small part of such a launch (7.6 of 33 us at cfg1), while what a wave
 // writes in one piece decides the write rate (round 2: half waves from 8 KB per full wave on, 3-12 %).  Round 4, on physically
@@ -2376,6 +2416,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
         apply_launch_hint(res, d->launch_hint);
         if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
         if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
+        a.cached_every = a.nt ? cached_every_policy(0, 0, true) : 0u;  // k_deal: only when forced (8x8 with 12 tiles -1 %, with 20 tiles 0)
         int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
         while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
         const size_t lds_request = lds_request_for_blocks_per_cu((size_t)waves * a.lds_wave_bytes, res.blocks_per_cu);
@@ -2397,6 +2438,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
     if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(false, (uint64_t)a.bpw * out_per_board);
+    a.cached_every = a.nt ? cached_every_policy(S, out_per_board * (uint64_t)d->n_boards, a.onehot != nullptr) : 0u;
     apply_launch_hint(res, d->launch_hint);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
@@ -2461,6 +2503,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     apply_launch_hint(res, d->launch_hint);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
     if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
+    a.cached_every = a.nt ? cached_every_policy(S, (uint64_t)d->n_boards * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)),
+                                                        a.onehot != nullptr) : 0u;
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
     while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;  // 32x32 with one-hot: 21 KiB per wave
     if ((size_t)waves * a.lds_wave_bytes > kMaxBlockLds) return TS_ERR_LIMIT;  // cannot happen within TS_MAX_*
@@ -2685,7 +2729,8 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_XCD_PIECE ? &g_xcd_piece
                                : key == TS_TUNE_DEAL ? &g_deal_enabled
                                : key == TS_TUNE_MT_WINDOW ? &g_mt_window
-                               : key == TS_TUNE_SMALL_BPW ? &g_small_bpw : nullptr;
+                               : key == TS_TUNE_SMALL_BPW ? &g_small_bpw
+                               : key == TS_TUNE_CACHED_EVERY ? &g_cached_every : nullptr;
   if (!knob) return -1;
   if (key == TS_TUNE_MT_WINDOW && value > kMtLongWindow) value = kMtLongWindow;  // output 623 wraps around to twisted word 0
   return value >= 0 ? knob->exchange(value) : knob->load();
