@@ -285,7 +285,7 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
                              * = the policy (the largest of 64 / 32 / 16 whose chunk of observation stays within 14 KB); 16 / 32 / 64 =
                              * forced (the remaining lanes idle) */
 #define TS_TUNE_CACHED_EVERY 9 /* launches beyond the Infinity Cache: every N-th wave writes its float32 observation with the cached
-                                * stores instead of nontemporal ones.  0 (default) = the policy (single-stream launches of up to 768
+                                * stores instead of nontemporal ones.  0 (default) = the policy (single-stream launches of up to 704
                                 * MiB: 16 for 3x3 .. 8x8 boards with one lane per board, 16 / 32 up to / above 512 MiB for boards above
                                 * 16x16, else none), 1 = never, N >= 2 = forced for every launch beyond the cache */
 int64_t ts_tuning(int32_t key, int64_t value);

@@ -2277,10 +2277,10 @@ uint32_t cached_every_policy(int S, uint64_t output_bytes, bool two_streams) {
   const int64_t forced = g_cached_every.load(std::memory_order_relaxed);
   if (forced == 1) return 0u;
   if (forced >= 2 && forced <= 0x7fffffff) return (uint32_t)forced;
-  if (two_streams || output_bytes > (768ull << 20)) return 0u;
+  if (two_streams || output_bytes > (704ull << 20)) return 0u;  // (measured up to 700 / 720 MB; at 800 MB 7x7 +1.9 %, the 4M 4x4 sibling +2.7 % in one run)
   if (S >= 3 && S <= 8) return 16u;
   // Boards above 16x16 (k_lines, 16-bit cells; r04_cached_every_wide_boards.log, thirteen shapes from 17x17 to 32x32): every 16th
-  // wave up to 512 MiB (-0.3 .. -8 %; 32x32 with 32 tiles 74.7 -> 68.8 us, 24x24 with 4 tiles 72.8 -> 66.8), every 32nd up to 768
+  // wave up to 512 MiB (-0.3 .. -8 %; 32x32 with 32 tiles 74.7 -> 68.8 us, 24x24 with 4 tiles 72.8 -> 66.8), every 32nd up to 704
   // MiB (-0.2 .. -4.8 %, one shape +1.3 %; every 16th there: +6 % at 20x20 with 10 tiles).  9x9 .. 16x16 go either way (cfg4 +1.5 %
   // even with every 32nd wave, 11x11 .. 13x13 -2.5 %): all-nontemporal.
   if (S > 16) return output_bytes <= (512ull << 20) ? 16u : 32u;
