@@ -2295,6 +2295,7 @@ uint32_t cached_every_policy(int S, uint64_t output_bytes, bool two_streams) {
 // half waves (9.6 / 13.8 KB), 7x7 and 8x8 QUARTER waves (9.4 / 12.3 KB: 7x7 98.9 -> 83.2, 8x8 with 4 tiles 95.5 -> 82.8,
 // with 8 tiles 101.8 -> 82.8: 0.80 -> 0.96 of the HBM roofline).  `primary`: bytes per board of the launch's first large
 // stream (float32 observation, else uint8 observation, else one-hot planes).
+constexpr uint64_t kHugeStreamBytes = 1200ull << 20;
 int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primary, uint64_t state_bytes, uint64_t n_boards) {
 #if TS_SMALL_OOC_BPW > 0
   return (out_of_cache && register_path) ? TS_SMALL_OOC_BPW : kWave;
@@ -2309,6 +2310,11 @@ int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primar
   // (Streams beyond 1 GiB - cfg3's learner re-encoding 8,388,608 gathered 4x4 boards: 1.6 GB - want the shorter chunk again:
   // full waves 284 us, half waves 250, while at 2M / 4M boards full waves win 56 / 113 against 64 / 127:
   // profiles/r04_learner_side_sweep.log)
+  // 7x7 / 8x8 beyond ~1.2 GiB are different again: their quarter waves (138,000 .. 180,000 one-wave blocks) fall to 0.62 - 0.75 of
+  // the roofline, half waves with one contiguous eighth per XCD (piece_policy) hold 0.87 - 0.88: 7x7 at 1.3 / 1.7 GB 248.6 -> 196.6 /
+  // 365.4 -> 256.6 us, 8x8 203.9 -> 195.5 / 296.9 -> 252.0 (at 1.0 GB quarter waves still win: 150 against 165;
+  // profiles/r04_large_batch_probe.log).
+  if (primary >= 12u * 49u && primary * n_boards > kHugeStreamBytes) return 32;
   const uint64_t limit = primary * n_boards > (1ull << 30) ? 7u * 1024u : 14u * 1024u;
   for (int bpw = kWave; bpw > 16; bpw >>= 1)
     if (primary * (uint64_t)bpw <= limit) return bpw;
@@ -2437,7 +2443,8 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
                                             (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7), (uint64_t)d->n_boards);
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
-    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(false, (uint64_t)a.bpw * out_per_board);
+    if (a.xcd_piece == 0xffffffffu)  // (streams beyond ~1.2 GiB in chunks of 16 KB and more - 7x7 / 8x8 half waves: eighths, see small_boards_per_wave)
+      a.xcd_piece = ((uint64_t)a.bpw * out_per_board >= 16u * 1024u && out_per_board * (uint64_t)d->n_boards > kHugeStreamBytes) ? 0u : piece_policy(false, (uint64_t)a.bpw * out_per_board);
     a.cached_every = a.nt ? cached_every_policy(S, out_per_board * (uint64_t)d->n_boards, a.onehot != nullptr) : 0u;
     apply_launch_hint(res, d->launch_hint);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;

@@ -1,0 +1,5 @@
+set -e
+mkdir -p gpurun_out
+timeout -k 10 900 python tools/large_batch_probe.py > gpurun_out/r04_large_batch_probe.log 2>&1 || { tail -20 gpurun_out/r04_large_batch_probe.log; exit 1; }
+MEM=torch timeout -k 10 900 python tools/large_batch_probe.py >> gpurun_out/r04_large_batch_probe.log 2>&1 || { tail -20 gpurun_out/r04_large_batch_probe.log; exit 1; }
+grep -v amdgpu.ids gpurun_out/r04_large_batch_probe.log
