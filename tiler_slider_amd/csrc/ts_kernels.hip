@@ -2244,6 +2244,25 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
 // from 6x6 up (cfg2 139 -> 125 us, 12x12 77 -> 73, 6x6 71 -> 67, 9x9 83.5 -> 79) -, none for short chunks (a 4x4 half
 // wave has six store instructions: 115 -> 194 us with two of them write-back).  profiles/r03_emit_edges_ab.log
 uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= 8u * 1024u ? 3u : 0u; }
+// The edge stores are a CACHED share of the stream - 1 KiB per edge instruction and chunk - and that share must stay small in
+// absolute terms for the kernels that also read a lot of state per board (k_lines: line tables and up to 255 tiles; k_deal): from
+// ~150 MB of edge stores per launch on they fall to half their rate (round 4, profiles/r04_large_batch_edges.log, r04_knee_probe.log;
+// HBM traffic per board unchanged: r04_pmc_scaling) - cfg4's shape at 1.4 GB 401.8 us with both edges, 214.4 with the last one only,
+// 212.0 with none (0.46 -> 0.87 of the roofline); at 2.4 GB 805.8 / 716.4 / 387.6; 16x16, 24x24, 12x12, 8x8 with 20 tiles alike.
+// (k_small's register forms do not care: 4x4 at 2.1 GB 0.91, cfg2 at 2M boards 0.945 with both edges.)
+// k_small's forms with little state per board do not care (4x4 and 5x5 with two tiles at 1 GB: both edges 149 / 146 us, one 154 /
+// 152 - 166, none 173 / 176; cfg2 at 2M boards 0.945 with both); from ~20 bytes of state per board on they do (at 1 GB: 4x4 with six
+// tiles 191.8 -> 165.4 us with the first edge only, 5x5 / 6 tiles 189.6 -> 152.9, 8x8 / 8 tiles 160.0 -> 137.0, 7x7 146.4 -> 138.4;
+// the any-tile-count path at 6x6 / 12 tiles 272 -> 234 at 1.4 GB: r04_large_batch_edges_small_boards*.log) - the cached share
+// competes with the state for the caches.  The cap is what one 28x28 board per wave at 700 MB needs (152 MB, 0.97 with both).
+// Beyond 1 GiB per launch a little less is tolerated (24x24 at 2.1 GB with one edge, 148 MiB: 425 us; with none: 344).
+uint32_t edge_policy_capped(uint64_t obs_chunk, uint64_t edge_instruction_sites, bool keep_first) {
+  uint32_t e = edge_policy(obs_chunk);
+  const uint64_t kCap = (obs_chunk * edge_instruction_sites > (1ull << 30) ? 128ull : 152ull) << 20;
+  if (e == 3u && 2u * 1024u * edge_instruction_sites > kCap) e = keep_first ? 1u : 2u;  // one edge instruction only
+  if (e != 0u && e != 3u && 1024u * edge_instruction_sites > kCap) e = 0u;
+  return e;
+}
 
 // Block -> board-range mapping of out-of-cache launches (KArgs.xcd_piece, xcd_contiguous_block).
 // Round 3 (ordinary allocations, where the same launch runs at one of two speeds depending on the physical pages behind the
@@ -2420,7 +2439,9 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
         // wave writes only 6 .. 12 KB - 8x8 / 12 tiles: 91.7 us with the large-board kernel's bound of 14 blocks per CU, 75.2 without
         Residency res = ooc_residency(a.nt != 0, true, true, (uint64_t)bpw * out_pb, T);
         apply_launch_hint(res, d->launch_hint);
-        if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
+        if (a.emit_edges == 0xffu)  // chunks (and 8 KiB pieces of the plane stream) that carry edge instructions
+          a.emit_edges = edge_policy_capped((uint64_t)bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch),
+                                                ((uint64_t)d->n_boards + bpw - 1) / bpw + (a.onehot ? (uint64_t)d->n_boards * C * a.onehot_ch / 8192u : 0u), false);
         if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
         a.cached_every = a.nt ? cached_every_policy(0, 0, true) : 0u;  // k_deal: only when forced (8x8 with 12 tiles -1 %, with 20 tiles 0)
         int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
@@ -2442,7 +2463,11 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, a.obs ? 12ull * C : a.obs_u8 ? 3ull * C : 4ull * C * a.onehot_ch,
                                             (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7), (uint64_t)d->n_boards);
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
-    if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
+    if (a.emit_edges == 0xffu) {
+      const uint64_t chunk = (uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch);
+      const uint64_t sites = ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw * ((a.obs && a.onehot) ? 2u : 1u);
+      a.emit_edges = (T + Tt + 4 * ((C + 31) / 32) + 7 >= 20) ? edge_policy_capped(chunk, sites, true) : edge_policy(chunk);
+    }
     if (a.xcd_piece == 0xffffffffu)  // (streams beyond ~1.2 GiB in chunks of 16 KB and more - 7x7 / 8x8 half waves: eighths, see small_boards_per_wave)
       a.xcd_piece = ((uint64_t)a.bpw * out_per_board >= 16u * 1024u && out_per_board * (uint64_t)d->n_boards > kHugeStreamBytes) ? 0u : piece_policy(false, (uint64_t)a.bpw * out_per_board);
     a.cached_every = a.nt ? cached_every_policy(S, out_per_board * (uint64_t)d->n_boards, a.onehot != nullptr) : 0u;
@@ -2508,7 +2533,9 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     Residency res = ooc_residency(a.nt != 0, true, false,
                                         (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)), T);
     apply_launch_hint(res, d->launch_hint);
-    if (a.emit_edges == 0xffu) a.emit_edges = edge_policy((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch));
+    if (a.emit_edges == 0xffu)
+      a.emit_edges = edge_policy_capped((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch),
+                                            ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw + (a.onehot ? (uint64_t)d->n_boards * C * a.onehot_ch / 8192u : 0u), false);
     if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
     a.cached_every = a.nt ? cached_every_policy(S, (uint64_t)d->n_boards * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)),
                                                         a.onehot != nullptr) : 0u;
