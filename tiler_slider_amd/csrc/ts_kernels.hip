@@ -2334,6 +2334,11 @@ int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primar
   // 365.4 -> 256.6 us, 8x8 203.9 -> 195.5 / 296.9 -> 252.0 (at 1.0 GB quarter waves still win: 150 against 165;
   // profiles/r04_large_batch_probe.log).
   if (primary >= 12u * 49u && primary * n_boards > kHugeStreamBytes) return 32;
+  // Boards up to 6x6 with 20 bytes of state per board and more (six tiles, say) want FULL waves beyond 1 GiB - fewer, wider state
+  // accesses - where the two-tile forms want shorter chunks: 5x5 / 6 tiles at 1.4 GB 308.5 us with quarter waves, 218.1 with full
+  // ones (0.63 -> 0.89), 4x4 / 6 tiles at 2.1 GB 522 -> 355, 6x6 / 6 tiles at 1.4 GB 248 -> 220, 6x6 / 3 tiles 225.5 -> 208.8
+  // (profiles/r04_large_batch_probe_small_boards.log).
+  if (primary * n_boards > (1ull << 30) && state_bytes >= 20u * n_boards) return kWave;
   const uint64_t limit = primary * n_boards > (1ull << 30) ? 7u * 1024u : 14u * 1024u;
   for (int bpw = kWave; bpw > 16; bpw >>= 1)
     if (primary * (uint64_t)bpw <= limit) return bpw;

@@ -10,7 +10,8 @@ L = _cabi.lib()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 mem = os.environ.get("MEM", "contiguous")
 print(f"output_memory={mem}")
-for S, T, K, mb in ((7, 5, 6, 1000), (7, 5, 6, 1300), (7, 5, 6, 1700), (8, 4, 8, 1300), (8, 4, 8, 1700), (6, 3, 4, 1700), (3, 1, 0, 1700)):
+DEFAULT = '7,5,6,1000;7,5,6,1300;7,5,6,1700;8,4,8,1300;8,4,8,1700;6,3,4,1700;3,1,0,1700'
+for S, T, K, mb in [tuple(int(v) for v in x.split(',')) for x in os.environ.get('CASES', DEFAULT).split(';')]:
     n = (mb * 1_000_000 // (12 * S * S)) // 256 * 256
     env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=3, multi_color=True, max_steps=2**30, auto_reset=True, output_memory=mem)
     env.reset()
