@@ -1062,3 +1062,41 @@ def test_main_entry_point_plays_the_cfg0_board(torch_cuda, capsys):
     assert capsys.readouterr().out.rstrip().endswith("not solved in 1 steps")
     with pytest.raises(SystemExit):
         main.main(["main.py", "DXR"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cached_every", [1, 2, 3, 16])
+@pytest.mark.parametrize("S,T,K,mc,N", [(3, 1, 0, False, 3001), (5, 2, 3, True, 2500), (6, 3, 4, True, 1999), (6, 12, 4, False, 1200), (8, 4, 8, True, 900), (8, 12, 8, True, 700),
+                                        (11, 6, 8, True, 300), (15, 32, 24, True, 130), (20, 10, 40, False, 70), (32, 32, 100, True, 33)])
+def test_cached_waves_and_edge_stores_are_speed_only(torch_cuda, oracle, out_of_cache_kernels, cached_every, S, T, K, mc, N):
+    """Round 4's store policies of launches beyond the Infinity Cache - every N-th wave writing with the cached stores
+    (ts_tuning(TS_TUNE_CACHED_EVERY): 1 = never, 2 / 3 / 16 forced, also for the kernels whose policy never picks it) crossed with
+    the write-back edge stores of a chunk (ts_dims.emit_edges: none / first / last / both, which the size cap of edge_policy_capped
+    switches between) - change which store instruction writes a byte, never the byte: every kernel family against the oracle."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    L = _cabi.lib()
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=4000 + S * 13 + T)
+    before = L.ts_tuning(_cabi.TUNE_CACHED_EVERY, cached_every)
+    try:
+        for edges in (1, 2, 3, 4):
+            ref = oracle.OracleBatch(S, mc, 9, blk, init, tgt)
+            env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=9, auto_reset=True, with_reward=True, with_onehot=edges == 4)
+            plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=9, auto_reset=True)
+            env._dims.emit_edges = plain._dims.emit_edges = edges
+            want0 = ref.reset()
+            np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
+            np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
+            for step in range(4):
+                act = oracle.fill_actions(N, seed=55 + S, step_index=step)
+                obs, done, info = env.step(torch.from_numpy(act))
+                want = ref.step(act, mode=oracle.MODE_AUTORESET, reward=True, onehot=edges == 4)
+                ctx = f"cached_every={cached_every} edges={edges} S={S} T={T} step={step}"
+                _assert_plain_step(plain, torch.from_numpy(act), ref, want, ctx)
+                np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"], err_msg=ctx)
+                np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+                np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
+                if edges == 4:
+                    np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
+    finally:
+        L.ts_tuning(_cabi.TUNE_CACHED_EVERY, before)
