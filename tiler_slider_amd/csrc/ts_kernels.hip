@@ -2249,7 +2249,6 @@ uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= 8u * 1024u ? 3u :
 // ~150 MB of edge stores per launch on they fall to half their rate (round 4, profiles/r04_large_batch_edges.log, r04_knee_probe.log;
 // HBM traffic per board unchanged: r04_pmc_scaling) - cfg4's shape at 1.4 GB 401.8 us with both edges, 214.4 with the last one only,
 // 212.0 with none (0.46 -> 0.87 of the roofline); at 2.4 GB 805.8 / 716.4 / 387.6; 16x16, 24x24, 12x12, 8x8 with 20 tiles alike.
-// (k_small's register forms do not care: 4x4 at 2.1 GB 0.91, cfg2 at 2M boards 0.945 with both edges.)
 // k_small's forms with little state per board do not care (4x4 and 5x5 with two tiles at 1 GB: both edges 149 / 146 us, one 154 /
 // 152 - 166, none 173 / 176; cfg2 at 2M boards 0.945 with both); from ~20 bytes of state per board on they do (at 1 GB: 4x4 with six
 // tiles 191.8 -> 165.4 us with the first edge only, 5x5 / 6 tiles 189.6 -> 152.9, 8x8 / 8 tiles 160.0 -> 137.0, 7x7 146.4 -> 138.4;
