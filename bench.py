@@ -61,20 +61,15 @@ def algorithmic_bytes_per_board_step(size, tiles, onehot, reward, multi_color=Tr
     return read + write
 
 
-def dominant_kernel(cfg, n, L):
-    """Name of the kernel ts_step launches for this config (the policy of ts_kernels.hip: launch())."""
-    S, T = cfg["size"], cfg["tiles"]
-    if S > 8:
-        return "k_lines"
-    out_bytes = (12 * S * S + (4 * S * S * (1 + 2 * T) if cfg["onehot"] else 0)) * n
-    two_per_lane = (2 <= S <= 5 and 1 <= T <= 8 and not cfg["onehot"] and n % 2 == 0 and out_bytes <= 256 << 20
-                    and n >= L.ts_tuning(_cabi_key_multi_min_boards(), -1))
-    return "k_multi" if two_per_lane else "k_small"
-
-
-def _cabi_key_multi_min_boards():
+def launch_description(env, outputs=None):
+    """What ts_step launches for this environment, from the library itself (ts_describe_launch: the code path the launch takes)."""
     from tiler_slider_amd import _cabi
-    return _cabi.TUNE_MULTI_MIN_BOARDS
+    if outputs is None:
+        outputs = ((_cabi.OUT_OBS if env.obs_dtype is not None and env._obs.dtype.is_floating_point else 0)
+                   | (_cabi.OUT_OBS_U8 if env.obs_dtype is not None and not env._obs.dtype.is_floating_point else 0)
+                   | (_cabi.OUT_REWARD if env._reward is not None else 0) | (_cabi.OUT_ONEHOT if env._onehot is not None else 0)
+                   | (_cabi.OUT_VALID | _cabi.OUT_VALID4 if env._valid is not None else 0))
+    return _cabi.describe_launch(env._dims, _cabi.OP_STEP, outputs)
 
 
 def pmc_traffic(config, boards):
@@ -187,8 +182,8 @@ def main():
     ap.add_argument("--obs-candidates", type=int, default=None,
                     help="VecTilerSliderEnv(obs_candidates=...): the fastest of up to k candidate observation buffers (environments "
                          "with one-hot planes run at one of two speeds by where the observation buffer lies, even in physically "
-                         "contiguous memory; ~2 ms per candidate at construction).  Default: the class default (8 for such "
-                         "environments, else 0); 0 = the first allocation")
+                         "contiguous memory; ~2 ms per candidate at construction).  Default: the class default (16 for such "
+                         "environments - at most 4 GiB of candidates in all: 13 at cfg2 -, else 0); 0 = the first allocation")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-halves-on-two-streams figure")
     ap.add_argument("--no-sibling", action="store_true", help="skip the out-of-cache sibling of a cache-resident config")
     ap.add_argument("--clock-warmup-ms", type=float, default=150.0,
@@ -381,6 +376,38 @@ def main():
         del big, acts
         torch.cuda.empty_cache()
 
+    # the same config at >= 3 GB per launch: the figure the Infinity Cache cannot help (roofline.hbm_asymptote)
+    asymptote = None
+    if world == 1 and args.config in ASYMPTOTE_BOARDS and not args.boards and not args.no_sibling:
+        asymptote = time_asymptote(args.config, device, L, stream, args.output_memory)
+
+    # cfg3's building blocks on one GPU: (a) the step into a ring of TWO observation buffers - what the overlapped hand-off of
+    # float32 / uint8 observations needs (obs_buffers=2; the ring's bytes, not the launch's, decide cache residency:
+    # ts_dims.ring_bytes) - and (b) the actor step that keeps NO observation (compact hand-off: the learner re-encodes)
+    double_buffered = actor = None
+    if world == 1 and not args.no_sibling and not cfg["onehot"]:
+        kw_twin = dict(multi_color=True, max_steps=2**30, device=device, auto_reset=True, with_reward=cfg["reward"])
+        e2 = VecTilerSliderEnv.from_arrays(cfg["size"], env._blk, env._init, env._tgt, obs_buffers=2, output_memory=args.output_memory, **kw_twin)
+        e2.reset()
+        us2 = time_env_steps(e2, ring, min(args.steps, 200), warm=20)
+        d2 = launch_description(e2)
+        double_buffered = {"obs_buffers": 2, "kernel": d2["name"], "kernel_us": us2, "frac": bps_cfg * n / us2 / 1e3 / HBM_PEAK_GBS,
+                           "achieved_GBps": bps_cfg * n / us2 / 1e3, "value": n / us2 * 1e6, "unit": "env-steps/s",
+                           "ring_bytes": e2._dims.ring_bytes, "out_of_cache": d2["out_of_cache"],
+                           "note": "ts_step into a ring of two observation buffers (what an overlapped gather needs); classified by the ring's bytes"}
+        del e2
+        ea = VecTilerSliderEnv.from_arrays(cfg["size"], env._blk, env._init, env._tgt, obs_dtype=None, **kw_twin)
+        ea.reset()
+        usa = time_env_steps(ea, ring, min(args.steps, 200), warm=20)
+        C_ = cfg["size"] ** 2
+        bpa = bps_cfg - 12 * C_
+        actor = {"kernel": launch_description(ea)["name"], "kernel_us": usa, "value": n / usa * 1e6, "unit": "env-steps/s",
+                 "algorithmic_bytes_per_board_step": bpa, "achieved_GBps": bpa * n / usa / 1e3, "frac": bpa * n / usa / 1e3 / HBM_PEAK_GBS,
+                 "note": "VecTilerSliderEnv(obs_dtype=None): ts_step_out.obs = NULL - the actor ranks of the compact hand-off; "
+                         "launch-bound (a few MB of state), so frac is not the yardstick"}
+        del ea
+        torch.cuda.empty_cache()
+
     # The other single-GPU configs of BASELINE.json (cfg2: 5x5 + one-hot + reward; cfg4: 15x15 / 32 tiles - the genuinely
     # HBM-bound ones), a few hundred ms each, so that the driver's one default run records all three: with the library's static
     # launch policy (placement_trials = 0), with the class default (launch policy rated at construction on the first
@@ -463,6 +490,8 @@ def main():
                                    + (", + one-hot + Manhattan reward" if cfg["onehot"] else ""),
                        "boards_per_gpu": n, "total_boards": total_boards, "obs": "float32 [N,S,S,3]",
                        "launch": "hipGraph" if graph is not None else "eager", "clock_warmup": clock_warmup,
+                       "clock_note": "steady-state-clock figure since round 4 (untimed clock warm-up before the W warm-up steps); rounds 1-3 "
+                                     "timed the first steps after idle, ~5 % slower: not comparable one-to-one",
                        # construction-time choice among candidate allocations of the output buffers (outside the
                        # timed region; only for batches beyond the Infinity Cache): VecTilerSliderEnv docstring
                        "placement_trials": args.placement_trials, "placement": env.placement_report, "output_memory": args.output_memory,
@@ -471,17 +500,23 @@ def main():
                                          "lines_lanes": env._dims.lines_lanes, "xcd_piece": env._dims.xcd_piece},
                        "parallelism": f"boards sharded over {world} GPU(s), no data-path collective",
                        "level_seed": hex(LEVEL_SEED), "action_seed": hex(ACTION_SEED)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # `bound`: "hbm" only where the 256 MiB Infinity Cache cannot help (>= 3 GB per launch).  A launch that fits the
+            # cache runs at the on-die cache / fabric write rate; one of 1 .. 12 x the cache has part of its stream absorbed
+            # between launches (algorithmic bytes / time is then an UPPER bound on HBM traffic).  `peak` is the HBM3E spec peak
+            # in every case; the HBM-bound figure of the same kernel and shape is `hbm_asymptote`.
+            "roofline": {"bound": "hbm" if bps * n >= 12 * INFINITY_CACHE_BYTES else ("infinity_cache" if cache_resident else "hbm+infinity_cache"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "working_set_over_infinity_cache": bps * n / INFINITY_CACHE_BYTES,
                          # the same from the wall clock of the timed region (host launch gaps included);
                          # `frac` is from HIP events on the launch stream
                          "frac_wall": achieved_wall / HBM_PEAK_GBS,
                          "frac_of_copy_ceiling": achieved / COPY_CEILING_GBS, "copy_ceiling": COPY_CEILING_GBS,
-                         "kernel": dominant_kernel(cfg, n, L),
+                         "kernel": launch_description(env)["name"], "launch": launch_description(env),
                          "kernel_us": kern_s * 1e6, "algorithmic_bytes_per_board_step": bps,
                          "algorithmic_bytes_per_launch": bps * n,
                          # a launch that moves less than the 256 MiB Infinity Cache runs at the on-die
-                         # cache / fabric write rate, not at the HBM rate: see "hbm_sibling"
+                         # cache / fabric write rate, not at the HBM rate: see "hbm_asymptote"
                          "cache_resident": cache_resident},
         }
         rec = pmc_traffic(args.config if n == CONFIGS[args.config]["boards"] else args.config + "_sibling_4m", n)
@@ -491,7 +526,15 @@ def main():
                                                   "correction; raw FETCH_SIZE %d B), separate passes, recorded in "
                                                   "profiles/traffic_pmc.json" % rec["fetch_bytes_raw"])
         if sibling is not None:
-            line["roofline"]["hbm_sibling"] = sibling
+            sibling["note"] = "the same kernel family at 4 x the boards: %.1f x the Infinity Cache - still cache-assisted, see hbm_asymptote" % (
+                sibling["algorithmic_bytes_per_launch"] / INFINITY_CACHE_BYTES)
+            line["roofline"]["sibling_3p4x_infinity_cache" if args.config == "cfg1" else "sibling_4x_boards"] = sibling
+        if asymptote is not None:
+            line["roofline"]["hbm_asymptote"] = asymptote
+        if double_buffered is not None:
+            line["double_buffered"] = double_buffered
+        if actor is not None:
+            line["actor_without_observation"] = actor
         if others is not None:
             line["other_configs"] = others
         if api is not None:
@@ -614,6 +657,60 @@ def time_learner_side(cfg, n_all, device, L, stream):
     return res
 
 
+ASYMPTOTE_BOARDS = {"cfg1": 1 << 24, "cfg2": 1 << 22, "cfg4": (1 << 20) + (1 << 18)}  # >= 3 GB of large outputs per launch
+
+
+def time_env_steps(env, acts, steps, warm=10):
+    """us per ts_step (HIP events on the launch stream) of an environment that is already reset."""
+    import torch
+    m = len(acts) - 1
+    for i in range(warm):
+        env.step_async(acts[i & m])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        env.step_async(acts[i & m])
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / steps
+
+
+def action_buffers(n, count, device, L, stream, offset=0):
+    import torch
+    from tiler_slider_amd import _cabi
+    acts = []
+    for i in range(count):
+        a = torch.empty(n, dtype=torch.uint8, device=device)
+        _cabi.check(L.ts_fill_actions(n, ACTION_SEED, offset, i, a.data_ptr(), stream), "ts_fill_actions")
+        acts.append(a)
+    return acts
+
+
+def time_asymptote(name, device, L, stream, output_memory="contiguous"):
+    """The same shape and outputs at >= 3 GB of large outputs per launch: twelve times the 256 MiB Infinity Cache and more, where
+    what the cache can absorb between two launches is a few per cent of the stream - the HBM-bound figure of this config's kernel
+    (every BASELINE config itself lies between 0.9 and 3.4 x the cache, where a third of the stream can be absorbed)."""
+    import torch
+    from tiler_slider_amd import VecTilerSliderEnv
+    cfg = CONFIGS[name]
+    n = ASYMPTOTE_BOARDS[name]
+    bps = algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
+    env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"], seed=LEVEL_SEED,
+                                   multi_color=True, max_steps=2**30, device=device, auto_reset=True, with_reward=cfg["reward"],
+                                   with_onehot=cfg["onehot"], output_memory=output_memory, obs_candidates=0)
+    env.reset()
+    us = time_env_steps(env, action_buffers(n, 2, device, L, stream), 10, warm=3)
+    desc = launch_description(env)
+    gbs = bps * n / us / 1e3
+    res = {"boards": n, "kernel": desc["name"], "kernel_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS, "algorithmic_bytes_per_launch": bps * n,
+           "times_infinity_cache": bps * n / INFINITY_CACHE_BYTES, "value": n / us * 1e6, "value_unit": "env-steps/s", "steps": 10,
+           "launch": {k: desc[k] for k in ("boards_per_wave", "cached_every", "emit_edges", "xcd_piece", "blocks_per_cu", "blocks")}}
+    del env
+    torch.cuda.empty_cache()
+    return res
+
+
 def time_config(name, trials, steps, device, L, stream):
     """Kernel time (HIP events on the launch stream) of one BASELINE config, first allocation and tuned."""
     import torch
@@ -628,7 +725,7 @@ def time_config(name, trials, steps, device, L, stream):
         acts.append(a)
     out = {"workload": f"{name}: {n:,} concurrent {cfg['size']}x{cfg['size']} boards, T={cfg['tiles']}, K={cfg['obstacles']}, multi_color"
                        + (", + one-hot + Manhattan reward" if cfg["onehot"] else ""),
-           "kernel": dominant_kernel(cfg, n, L), "algorithmic_bytes_per_board_step": bps, "algorithmic_bytes_per_launch": bps * n,
+           "algorithmic_bytes_per_board_step": bps, "algorithmic_bytes_per_launch": bps * n,
            "steps": steps}
     # first_allocation_contiguous_memory: THE CLASS DEFAULT - output buffers in physically contiguous memory, the library's
     # static launch policy, nothing measured at construction (placement_trials = 0): the same in every process;
@@ -656,6 +753,7 @@ def time_config(name, trials, steps, device, L, stream):
         torch.cuda.synchronize(device)
         us = e0.elapsed_time(e1) * 1e3 / steps
         gbs = bps * n / us / 1e3
+        out["kernel"] = launch_description(env)["name"]
         out[key] = {"placement_trials": k, "output_memory": mem, "kernel_us": us, "value": n / us * 1e6, "unit": "env-steps/s", "achieved": gbs,
                     "achieved_unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS,
                     "launch_policy": {"launch_hint": env._dims.launch_hint, "emit_edges": env._dims.emit_edges, "lines_lanes": env._dims.lines_lanes, "xcd_piece": env._dims.xcd_piece},
@@ -665,23 +763,25 @@ def time_config(name, trials, steps, device, L, stream):
     rec = pmc_traffic(name, n)
     if rec is not None:
         out["traffic"] = rec["write_bytes"] + rec["fetch_bytes_x2"]
+    out["hbm_asymptote"] = time_asymptote(name, device, L, stream)
     return out
 
 
 def time_gathers(env, ring, world, n, dist, torch, device, steps):
     """Step + hand-off to a single learner, three ways: (a) RCCL all-gather of the float32
-    observations (what north_star names); (b) all-gather of the compact state (cell ids) and
-    re-encoding on the learner side with ts_encode; (c) all-gather of uint8 observations and one
-    ts_expand_u8 on the learner.  Each is timed serially (step k, then gather k, on one stream)
-    and overlapped: the environment cycles through two observation buffers, gather k runs on
-    RCCL's stream while step k+1 writes the other buffer, and step k+2 waits for gather k."""
+    observations (what north_star names); (b) all-gather of the compact state (cell ids + flags, from actors
+    that keep NO observation: obs_dtype=None) and re-encoding on the learner side with ts_encode; (c) all-gather of uint8
+    observations and one ts_expand_u8 on the learner.  Every form delivers the step's flags too (done follows from them).
+    Each is timed serially (step k, then gather k, on one stream) and overlapped: the environment cycles through two
+    observation buffers, gather k runs on RCCL's stream while step k+1 writes the other buffer, and step k+2 waits for gather k;
+    and each as an all-gather (every rank receives everything) and as a gather to rank 0 alone (`*_to_root`)."""
     from tiler_slider_amd import VecTilerSliderEnv
     from tiler_slider_amd.distributed import ObservationGatherer
 
     def twin(obs_dtype):
         e = VecTilerSliderEnv.from_arrays(env.size, env._blk, env._init, env._tgt, multi_color=env.multi_color,
                                           max_steps=env.max_steps, device=device, auto_reset=True, obs_dtype=obs_dtype,
-                                          obs_buffers=2)
+                                          obs_buffers=1 if obs_dtype is None else 2)
         e.reset()
         return e
 
@@ -697,34 +797,38 @@ def time_gathers(env, ring, world, n, dist, torch, device, steps):
         return float(dt[0])
 
     out = {}
-    e32 = twin("float32")
-    g32 = ObservationGatherer(e32, world)
-    modes = [("obs_f32", e32, g32, lambda e, g, async_op: g.gather_observations(e._obs, async_op=async_op)),
-             ("compact_state_then_encode", e32, g32, lambda e, g, async_op: g.gather_compact_and_encode(async_op=async_op))]
-    e8 = twin("uint8")
-    g8 = ObservationGatherer(e8, world)
-    modes.append(("obs_u8_then_expand", e8, g8, lambda e, g, async_op: g.gather_u8_and_expand(e._obs, async_op=async_op)))
-    for name, e, g, fn in modes:
-        fn(e, g, False)  # warm-up (RCCL channel set-up)
+    e32, eact, e8 = twin("float32"), twin(None), twin("uint8")
+    forms = [("obs_f32", e32, lambda e, g, a: g.gather_observations(e._obs, async_op=a)),
+             ("compact_state_then_encode", eact, lambda e, g, a: g.gather_compact_and_encode(async_op=a)),
+             ("obs_u8_then_expand", e8, lambda e, g, a: g.gather_u8_and_expand(e._obs, async_op=a))]
+    for root, suffix in ((None, ""), (0, "_to_root")):
+        for name, e, fn in forms:
+            g = ObservationGatherer(e, world, root=root)
+            fn(e, g, False)  # warm-up (RCCL channel set-up)
 
-        def serial():
-            for i in range(steps):
-                e.step_async(ring[i & 15])
-                fn(e, g, False)
+            def serial():
+                for i in range(steps):
+                    e.step_async(ring[i & 15])
+                    fn(e, g, False)
 
-        def overlapped():
-            prev = None
-            for i in range(steps):
-                e.step_async(ring[i & 15])          # writes observation buffer i % 2
-                if prev is not None:
-                    prev.wait()                     # gather i-1 has read buffer (i-1) % 2 ...
-                prev = fn(e, g, True)               # ... gather i starts behind step i, beside step i+1
-            prev.wait()
+            def overlapped():
+                prev = None
+                for i in range(steps):
+                    e.step_async(ring[i & 15])          # writes observation buffer i % 2
+                    if prev is not None:
+                        prev.wait()                     # gather i-1 has read buffer (i-1) % 2 ...
+                    prev = fn(e, g, True)               # ... gather i starts behind step i, beside step i+1
+                prev.wait()
 
-        ts, to = timed(serial), timed(overlapped)
-        out[name] = {"value": n * world * steps / ts, "value_overlapped": n * world * steps / to, "unit": "env-steps/s",
-                     "steps": steps, "ms_per_step_serial": ts / steps * 1e3, "ms_per_step_overlapped": to / steps * 1e3,
-                     "bytes_per_rank_per_step": g.bytes_per_step[name]}
+            ts, to = timed(serial), timed(overlapped)
+            out[name + suffix] = {"value": n * world * steps / ts, "value_overlapped": n * world * steps / to, "unit": "env-steps/s",
+                                  "steps": steps, "ms_per_step_serial": ts / steps * 1e3, "ms_per_step_overlapped": to / steps * 1e3,
+                                  "bytes_per_rank_per_step": g.bytes_per_step[name], "delivers": "obs + flags (done)",
+                                  "collective": "all_gather" if root is None else "gather to rank 0",
+                                  "actor_step": ("no observation (obs_dtype=None)" if e is eact else
+                                                 "ring of two observation buffers, %s forms" % ("out-of-cache" if e._dims.ring_bytes > INFINITY_CACHE_BYTES else "cache-resident"))}
+            del g
+            torch.cuda.empty_cache()
     return out
 
 

@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define TS_ABI_VERSION 5
+#define TS_ABI_VERSION 6
 #define TS_MAX_SIZE 32   /* cell ids: uint8 up to 16x16, uint16 up to 32x32 (ts_cell_bytes) */
 #define TS_MAX_TILES 255 /* observation stores tile index + 1 in one byte */
 
@@ -120,6 +120,12 @@ typedef struct ts_dims {
                         * is tuned on physically contiguous output buffers (hipExtMallocWithFlags(hipDeviceMallocContiguous),
                         * what the shipped host code allocates beyond 256 MiB): cfg2 122 -> 118 us, cfg4 114 -> 107 against
                         * eighths.  On ordinary allocations eighths win on some ("fast") buffers and lose on others. */
+  int64_t ring_bytes;  /* ABI v6.  0 = this launch's large outputs are all that matters.  Otherwise: the bytes of ALL the large
+                        * output buffers that successive launches of this environment cycle through (an observation ring of k
+                        * buffers: k x the observation bytes, plus the one-hot planes).  A launch is classified as cache-resident
+                        * or beyond the 256 MiB Infinity Cache by max(its own output bytes, ring_bytes): two alternating 201-MB
+                        * buffers are a 402-MB working set, and agent-scope stores into it are the wrong policy
+                        * (profiles/r05_ring_probe.log).  Speed only. */
 } ts_dims;
 
 typedef struct ts_state {
@@ -239,6 +245,55 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
 
 /* --- launch policy ------------------------------------------------------------ */
 
+/* What ONE call of the hot path would launch (ABI v6): kernel family and template form, grid, LDS request and the policy
+ * fields the kernel receives - computed by the very code path ts_step / ts_reset / ts_encode / ... take before they launch, so
+ * it can be read (and pinned by a test) without a GPU.  Nothing is launched and no device is touched.
+ *   op            TS_OP_STEP / TS_OP_RESET / TS_OP_OBSERVE (ts_encode, ts_valid_moves, ts_is_won, ts_reward, ...)
+ *   outputs_mask  TS_OUT_* bits of the outputs the call would bind (ts_step_out's non-NULL pointers; ts_reset: TS_OUT_OBS or 0;
+ *                 ts_is_won: TS_OUT_FLAGS).  All buffers are assumed aligned as the shipped host code allocates them.
+ * The per-call policy fields of `dims` (launch_hint, emit_edges, lines_lanes, xcd_piece, ring_bytes) and the process-wide knobs of
+ * ts_tuning apply exactly as they would to the launch.  Returns TS_OK or the status the launch itself would return. */
+#define TS_OP_STEP 0u
+#define TS_OP_RESET 1u
+#define TS_OP_OBSERVE 2u
+#define TS_OUT_OBS 0x01u
+#define TS_OUT_REWARD 0x02u
+#define TS_OUT_ONEHOT 0x04u
+#define TS_OUT_VALID 0x08u
+#define TS_OUT_OBS_U8 0x10u
+#define TS_OUT_VALID4 0x20u
+#define TS_OUT_FLAGS 0x40u
+#define TS_KERNEL_NONE 0  /* empty batch: nothing is launched */
+#define TS_KERNEL_SMALL 1 /* k_small<S, TFIX, EXTRAS, NT>: S <= 8, one board per lane */
+#define TS_KERNEL_MULTI 2 /* k_multi<S, TFIX, EXTRAS, G>: S <= 5, cache-resident, G boards per lane */
+#define TS_KERNEL_DEAL 3  /* k_deal<S, G, TPL, EXTRAS, NT>: 7x7 / 8x8 with 9 .. 64 tiles, G lanes per board */
+#define TS_KERNEL_LINES 4 /* k_lines<WIDE, LPB, TPL, NT, EXTRAS>: S 9 .. 32 from the tables of ts_prepare */
+#define TS_KERNEL_STATE 5 /* k_state<WIDE, EXTRAS>: S 9 .. 32, no image output: one board per lane */
+typedef struct ts_launch_desc {
+  int32_t kernel;          /* TS_KERNEL_* */
+  int32_t out_of_cache;    /* 1 = the launch (or the ring it writes into, ts_dims.ring_bytes) counts as beyond the Infinity Cache:
+                              nontemporal stores, one-wave blocks, bounded residency */
+  int32_t lanes_per_board; /* 1, or the lanes a board's tiles / lines are dealt over (k_deal, k_lines) */
+  int32_t boards_per_lane; /* 1, or 2 (k_multi) */
+  int32_t boards_per_wave; /* boards one wave carries (idle upper lanes excluded) */
+  int32_t tiles_per_lane;  /* TFIX (k_small / k_multi; 0 = any tile count, through LDS) or TPL (k_deal, k_lines) */
+  int32_t extras;          /* 1 = the instantiation with legality mask / reward / one-hot code */
+  int32_t wide;            /* 1 = 16-bit cell ids (S > 16) */
+  int32_t cached_every;    /* every N-th wave stores its observation with cached stores (0 = none) */
+  int32_t emit_edges;      /* bit 0 / 1: first / last store instruction of a chunk is a write-back store */
+  int32_t xcd_piece;       /* 0 = one contiguous eighth of the batch per XCD; P = pieces of P blocks; -1 = not applicable */
+  int32_t waves_per_block;
+  int32_t blocks_per_cu;   /* resident blocks per CU the LDS request admits (0 = not bounded by the policy) */
+  int32_t lds_bytes_block; /* dynamic LDS requested per block */
+  int32_t lds_bytes_used;  /* of which the block uses */
+  int32_t reserved;
+  int64_t blocks;          /* grid size */
+  int64_t output_bytes;    /* bytes of large outputs (observation, one-hot planes, uint8 observation) this launch writes */
+  int64_t resident_bytes;  /* what the launch was classified by: max(output_bytes, ts_dims.ring_bytes) */
+  char name[64];           /* as rocprofv3 prints it, e.g. "k_small<5, 2, true, true>" */
+} ts_launch_desc;
+int32_t ts_describe_launch(const ts_dims *dims, uint32_t op, uint32_t outputs_mask, ts_launch_desc *desc);
+
 /* Process-wide launch-policy knobs.  They choose between kernels that produce identical
  * results (every policy is under the same parity tests), so they affect speed only.
  *   TS_TUNE_MULTI_MIN_BOARDS  batch size from which cache-resident launches of boards up to
@@ -288,6 +343,9 @@ int32_t ts_prepare(const ts_dims *dims, const ts_state *st, uint32_t *lines, voi
                                 * stores instead of nontemporal ones.  0 (default) = the policy (single-stream launches of up to 704
                                 * MiB: 16 for 3x3 .. 8x8 boards with one lane per board, 16 / 32 up to / above 512 MiB for boards above
                                 * 16x16, else none), 1 = never, N >= 2 = forced for every launch beyond the cache */
+#define TS_TUNE_STATE_ONLY 10 /* 1 (default): above 8x8, launches with no image output (ts_is_won, ts_valid_moves(4), multi-colour
+                               * ts_reward, ts_step / ts_reset without an observation) run one board per lane (k_state); 0: they stay
+                               * on the image kernel (k_lines) - kept for A/B and as the parity cross-check */
 int64_t ts_tuning(int32_t key, int64_t value);
 
 /* --- synthetic inputs (bench / tests) --------------------------------------- */

@@ -20,7 +20,7 @@ MODE_STRICT, MODE_AUTORESET = 0, 1
 class Dims(C.Structure):
     _fields_ = [("n_boards", C.c_int64), ("size", C.c_int32), ("n_tiles", C.c_int32), ("n_targets", C.c_int32),
                 ("multi_color", C.c_int32), ("max_steps", C.c_int32), ("launch_hint", C.c_int32), ("emit_edges", C.c_int32),
-                ("lines_lanes", C.c_int32), ("xcd_piece", C.c_int32)]  # the whole ts_dims of include/tiler_slider.h
+                ("lines_lanes", C.c_int32), ("xcd_piece", C.c_int32), ("ring_bytes", C.c_int64)]  # the whole ts_dims of include/tiler_slider.h
 
 
 class State(C.Structure):

@@ -187,7 +187,7 @@ void tso_state_array(int32_t S, const uint8_t *blocked, int32_t T, const int32_t
 static int check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
   if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 ||
-      d->emit_edges < 0 || d->emit_edges > 4 || d->xcd_piece < 0 || d->xcd_piece > (1 << 20) ||
+      d->emit_edges < 0 || d->emit_edges > 4 || d->xcd_piece < 0 || d->xcd_piece > (1 << 20) || d->ring_bytes < 0 ||
       (d->lines_lanes != 0 && d->lines_lanes != 4 && d->lines_lanes != 8 && d->lines_lanes != 16 && d->lines_lanes != 32) || /* the launch-policy fields are ignored here, but the same ranges are refused (include/tiler_slider.h) */
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;

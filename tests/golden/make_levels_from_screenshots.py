@@ -35,12 +35,20 @@ def main():
         blocked[i, :len(l.blocked_locations)] = np.asarray(l.blocked_locations, np.int8).reshape(-1, 2)
         tiles[i, :len(l.initial_locations)] = np.asarray(l.initial_locations, np.int8).reshape(-1, 2)
         targets[i, :len(l.target_locations)] = np.asarray(l.target_locations, np.int8).reshape(-1, 2)
+    # the least number of moves that solves each level (breadth-first over the CPU oracle: tests/level_solver.py) - an
+    # independent property of the parse: every level of the game is solvable, and its packs are sorted by this number
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import level_solver
+    from oracle import binding as orc
+    won0 = lambda S, mc, blk, init, tgt: orc.OracleBatch(S, mc, 2**30, blk, init, tgt).won() != 0
+    solved = level_solver.solve_all(list(zip(loader.files, parsed)), levels.pack_levels, level_solver.oracle_expand(orc), won0)
+    assert all(solved[f] is not None for f in loader.files), [f for f in loader.files if solved[f] is None]
     out = os.path.join(ROOT, "tests", "golden", "levels_from_screenshots.npz")
     np.savez_compressed(out, names=np.array(loader.files), size=np.array([l.size for l in parsed], np.int8),
                         multi=np.array([l.multiple_colors for l in parsed], bool),
                         n_blocked=np.array([len(l.blocked_locations) for l in parsed], np.int16),
                         n_tiles=np.array([len(l.initial_locations) for l in parsed], np.int16),
-                        blocked=blocked, tiles=tiles, targets=targets)
+                        blocked=blocked, tiles=tiles, targets=targets, min_moves=np.array([solved[f] for f in loader.files], np.int16))
     print(out, os.path.getsize(out), "bytes;", n, "levels")
 
 

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(L, sym), f"{sym} declared in include/tiler_slider.h but not exported"
     assert set(declared) == set(_cabi.EXPORTS)
-    assert L.ts_abi_version() == _cabi.ABI_VERSION == 5
+    assert L.ts_abi_version() == _cabi.ABI_VERSION == 6
     assert [L.ts_lines_words(s) for s in (0, 8, 9, 16, 17, 32, 33)] == [0, 0, 32, 32, 128, 128, 0]
     assert _cabi.limits() == (32, 255)
     assert [L.ts_blk_words(s) for s in (1, 4, 5, 6, 8, 15, 16, 20, 32)] == [1, 1, 1, 2, 2, 8, 8, 13, 32]

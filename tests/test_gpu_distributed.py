@@ -61,30 +61,51 @@ def test_overlapped_gathers_over_rccl_world1(rccl_world1, shape):
     e32 = VecTilerSliderEnv.random(N, **kw)
     e8 = VecTilerSliderEnv.random(N, obs_dtype="uint8", **kw)
     assert (e32._lines is not None) == (S > 8) and e32._pos.dtype == (torch.uint8 if S <= 16 else torch.int16)
+    # the actor of the compact hand-off keeps no observation at all (obs_dtype=None); gathered to a root (rank 0 = this rank)
+    kw1 = dict(kw, obs_buffers=1)
+    eact = VecTilerSliderEnv.random(N, obs_dtype=None, with_reward=True, **kw1)
     g32, g8 = ObservationGatherer(e32, 1), ObservationGatherer(e8, 1)
+    gact = ObservationGatherer(eact, 1, root=0, with_step_count=True)
     assert g32.counts == [N] and g32.equal and (g32.lines_flat is not None) == (S > 8)
-    modes = [("obs_f32", e32, lambda a: g32.gather_observations(e32._obs, async_op=a)),
-             ("compact", e32, lambda a: g32.gather_compact_and_encode(async_op=a)),
-             ("obs_u8", e8, lambda a: g8.gather_u8_and_expand(e8._obs, async_op=a))]
+    assert e32._dims.ring_bytes == 2 * e32._obs.numel() * 4 and eact._dims.ring_bytes == 0 and eact._obs is None
+    modes = [("obs_f32", e32, g32, lambda a: g32.gather_observations(e32._obs, async_op=a)),
+             ("compact", e32, g32, lambda a: g32.gather_compact_and_encode(async_op=a)),
+             ("obs_u8", e8, g8, lambda a: g8.gather_u8_and_expand(e8._obs, async_op=a)),
+             ("compact, actor without observation, gather to root", eact, gact, lambda a: gact.gather_compact_and_encode(async_op=a))]
     steps = 8
-    for name, env, fn in modes:
+    for name, env, g, fn in modes:
         env.reset()
         acts = [_actions(torch, env, i) for i in range(steps)]
         assert torch.equal(fn(False), env.encode(torch.empty_like(g32.obs_all))), (name, "blocking")
         expect, prev = [], None
         for i in range(steps):
             env.step_async(acts[i])
-            expect.append(env.encode(torch.empty_like(g32.obs_all)))  # float32 image of the boards after step i
+            # float32 image of the boards after step i, and what else step() returned: flags, done, reward, step counters
+            expect.append((env.encode(torch.empty_like(g32.obs_all)), env._flags.clone(), env._done.clone().bool(),
+                           None if env._reward is None else env._reward.clone(), env._step_count.clone()))
             if prev is not None:
                 got = prev.wait()
-                assert torch.equal(got, expect[i - 1]), (name, "gather", i - 1)
+                _check_handoff(torch, got, prev.info, expect[i - 1], (name, "gather", i - 1))
             prev = fn(True)
-        assert torch.equal(prev.wait(), expect[-1]), (name, "last")
+        _check_handoff(torch, prev.wait(), prev.info, expect[-1], (name, "last"))
+        assert bool(expect[-1][2].any()), "episodes of 5 steps: some boards must be done after 8"
         torch.cuda.synchronize()
     with pytest.raises(ValueError):  # async gather of a single-buffered environment would race with the next step
         one = VecTilerSliderEnv.random(64, size=4, num_tiles=2, num_obstacles=2)
         one.reset()
         ObservationGatherer(one, 1).gather_observations(async_op=True)
+
+
+def _check_handoff(torch, obs, info, want, ctx):
+    """A finished hand-off against (obs, flags, done, reward or None, step_count) cloned at that step."""
+    assert torch.equal(obs, want[0]), (ctx, "obs")
+    assert torch.equal(info["flags"], want[1]), (ctx, "flags")
+    assert torch.equal(info["done"], want[2]), (ctx, "done")
+    assert torch.equal(info["is_won"], (want[1] & 1) != 0) and torch.equal(info["timeout"], (want[1] & 8) != 0), (ctx, "bits")
+    if want[3] is not None and "reward" in info:
+        assert torch.equal(info["reward"], want[3]), (ctx, "reward")
+    if "step_count" in info:
+        assert torch.equal(info["step_count"], want[4]), (ctx, "step_count")
 
 
 class _Loopback:
@@ -109,6 +130,26 @@ class _Loopback:
             return None
         return all_gather
 
+    def gather_fn(self, rank, root):
+        """gather_fn for the same threads-as-ranks: only `root` receives (out_u8 is None elsewhere)."""
+        import torch
+
+        def gather(out_u8, shard_u8, async_op):
+            torch.cuda.synchronize()
+            self.slots[rank] = shard_u8
+            self.bar.wait(timeout=120)
+            if rank == root:
+                nb = shard_u8.numel()
+                for r in range(self.world):
+                    assert self.slots[r].numel() == nb
+                    out_u8[r * nb:(r + 1) * nb].copy_(self.slots[r])
+                torch.cuda.synchronize()
+            else:
+                assert out_u8 is None
+            self.bar.wait(timeout=120)
+            return None
+        return gather
+
 
 # name: (S, T, K, total, world): unequal shards on odd sizes (5x5: 300 B per board, 9x9: 972 B: offsets off 16 B),
 # a three-way split, lines tables, int16 cells; one equal case
@@ -124,41 +165,58 @@ def test_gathers_with_threads_as_ranks(case):
     assert torch.cuda.is_available()
     S, T, K, total, world = THREAD_CASES[case]
     kw = dict(size=S, num_tiles=T, num_obstacles=K, seed=31, multi_color=True, max_steps=4, auto_reset=True)
-    whole = VecTilerSliderEnv.random(total, **kw)
+    whole = VecTilerSliderEnv.random(total, with_reward=True, **kw)
     whole.reset()
     steps = 5
     expect = []
     for i in range(steps):
         whole.step_async(_actions(torch, whole, i))
-        expect.append(whole.encode().clone())
+        expect.append((whole.encode().clone(), whole._flags.clone(), whole._done.clone().bool(), whole._reward.clone(), whole._step_count.clone()))
     torch.cuda.synchronize()
-    loop = _Loopback(world)
+    assert bool(expect[-1][2].any()) or total < 50
+    loop, loop_root = _Loopback(world), _Loopback(world)
+    root = world - 1
     errors = []
 
     def rank_main(rank):
         try:
             torch.cuda.set_device(0)
             lo, hi = shard_bounds(total, world, rank)
-            e32 = make_sharded_env(total, rank, world, obs_buffers=2, **kw)
+            e32 = make_sharded_env(total, rank, world, obs_buffers=2, with_reward=True, **kw)
             e8 = make_sharded_env(total, rank, world, obs_buffers=2, obs_dtype="uint8", **kw)
-            g32 = ObservationGatherer(e32, world, all_gather_fn=loop.fn(rank))
-            g8 = ObservationGatherer(e8, world, all_gather_fn=loop.fn(rank))
+            eact = make_sharded_env(total, rank, world, obs_dtype=None, with_reward=True, **kw)  # an actor without observation
+            g32 = ObservationGatherer(e32, world, all_gather_fn=loop.fn(rank), rank=rank)
+            g8 = ObservationGatherer(e8, world, all_gather_fn=loop.fn(rank), rank=rank)
+            # ... whose cells, flags, reward and step counters are gathered to ONE root (the last rank)
+            gact = ObservationGatherer(eact, world, all_gather_fn=loop_root.fn(rank), gather_fn=loop_root.gather_fn(rank, root), rank=rank,
+                                       root=root, with_step_count=True)
+            assert gact.receives == (rank == root) and (gact.obs_all is None) == (rank != root)
             assert g32.counts == [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
             assert g32.equal == (total % world == 0) and g32.obs_all.shape[0] == total
-            e32.reset(), e8.reset()
+            e32.reset(), e8.reset(), eact.reset()
             for i in range(steps):
                 e32.step_async(_actions(torch, e32, i, lo))
                 e8.step_async(_actions(torch, e8, i, lo))
-                for name, got in (("obs_f32", g32.gather_observations(e32._obs)),
-                                  ("compact", g32.gather_compact_and_encode()),
-                                  ("obs_u8", g8.gather_u8_and_expand(e8._obs)),
-                                  ("compact async", g32.gather_compact_and_encode(async_op=True).wait()),
-                                  ("obs_u8 async", g8.gather_u8_and_expand(e8._obs, async_op=True).wait())):
+                eact.step_async(_actions(torch, eact, i, lo))
+                for name, g, call in (("obs_f32", g32, lambda: g32.gather_observations(e32._obs)),
+                                      ("compact", g32, lambda: g32.gather_compact_and_encode()),
+                                      ("obs_u8", g8, lambda: g8.gather_u8_and_expand(e8._obs)),
+                                      ("compact async", g32, lambda: g32.gather_compact_and_encode(async_op=True).wait()),
+                                      ("obs_u8 async", g8, lambda: g8.gather_u8_and_expand(e8._obs, async_op=True).wait())):
+                    got = call()
                     torch.cuda.synchronize()
-                    assert torch.equal(got, expect[i]), (case, rank, i, name)
+                    _check_handoff(torch, got, g.info, expect[i], (case, rank, i, name))
+                got = gact.gather_compact_and_encode()
+                torch.cuda.synchronize()
+                if rank == root:
+                    _check_handoff(torch, got, gact.info, expect[i], (case, rank, i, "actor without observation -> root"))
+                    assert "reward" in gact.info and "step_count" in gact.info
+                else:
+                    assert got is None and gact.info is None
         except BaseException as e:  # noqa: BLE001 - reported by the main thread
             errors.append((rank, repr(e)))
             loop.bar.abort()
+            loop_root.bar.abort()
 
     threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
     for t in threads:

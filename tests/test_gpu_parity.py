@@ -86,6 +86,21 @@ def _assert_plain_step(plain, act, ref, want, ctx=""):
     np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"], err_msg=ctx)
 
 
+def _assert_bare_step(bare, act, ref, want, ctx="", extras=False):
+    """One step of an environment that keeps NO observation (obs_dtype=None: ts_step_out.obs = NULL - above 8x8 the
+    one-board-per-lane kernel k_state, below the same kernels without their image) against the oracle."""
+    obs, done, info = bare.step(act)
+    assert obs is None
+    np.testing.assert_array_equal(bare.positions.cpu().numpy().astype(np.int64), ref.pos.astype(np.int64), err_msg=ctx)
+    np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
+    np.testing.assert_array_equal(bare.step_count.cpu().numpy(), ref.step_count, err_msg=ctx)
+    np.testing.assert_array_equal(done.cpu().numpy(), ref.done != 0, err_msg=ctx)
+    if extras:
+        np.testing.assert_array_equal(info["reward"].cpu().numpy(), want["reward"], err_msg=ctx)
+        np.testing.assert_array_equal(bare._valid.cpu().numpy(), want["valid"], err_msg=ctx)
+        np.testing.assert_array_equal(info["valid_moves"].cpu().numpy(), want["valid4"] != 0, err_msg=ctx)
+
+
 # (S, T, K, multi_color, N, max_steps): ragged N (not a multiple of 64 / of 4), every kernel variant
 RANDOM_SHAPES = [
     (1, 1, 0, False, 67, 5), (2, 1, 1, True, 130, 7), (3, 1, 0, False, 1027, 9), (3, 2, 2, True, 513, 9),
@@ -141,9 +156,15 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     # the same levels without the optional outputs: the plain kernels (k_small<EXTRAS = false>,
     # and k_lines from 9x9 on, which works from the per-level tables of ts_prepare)
     plain = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps, auto_reset=autoreset)
+    # and without any observation: the state-only launches (round 5) - with the optional outputs and without
+    bare = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps, auto_reset=autoreset, obs_dtype=None)
+    bare_x = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps, auto_reset=autoreset, obs_dtype=None,
+                                           with_reward=True, with_valid_moves=True)
     want0 = ref.reset()
     np.testing.assert_array_equal(env.reset().cpu().numpy(), want0)
     np.testing.assert_array_equal(plain.reset().cpu().numpy(), want0)
+    assert bare.reset() is None and bare_x.reset() is None
+    np.testing.assert_array_equal(bare.positions.cpu().numpy(), ref.pos)
     env8 = None
     if with_u8:
         env8 = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=max_steps, auto_reset=autoreset,
@@ -158,6 +179,8 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
         want = ref.step(act, mode=mode, reward=True, onehot=True, valid=True, valid4=True)
         ctx = f"S={S} T={T} step={step}"
         _assert_plain_step(plain, torch.from_numpy(act), ref, want, ctx)
+        _assert_bare_step(bare, torch.from_numpy(act), ref, want, ctx + " no observation")
+        _assert_bare_step(bare_x, torch.from_numpy(act), ref, want, ctx + " no observation, reward + legality mask", extras=True)
         np.testing.assert_array_equal(env.positions.cpu().numpy(), ref.pos, err_msg=ctx)
         np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"], err_msg=ctx)
         np.testing.assert_array_equal(env.step_count.cpu().numpy(), ref.step_count, err_msg=ctx)
@@ -183,6 +206,18 @@ def test_random_boards_vs_oracle(torch_cuda, oracle, S, T, K, mc, N, max_steps, 
     np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
     np.testing.assert_array_equal(plain.encode().cpu().numpy(), ref.encode())
     np.testing.assert_array_equal(plain.is_won().cpu().numpy(), ref.won() != 0)
+    np.testing.assert_array_equal(bare.encode().cpu().numpy(), ref.encode())  # an observation on request, float32 by default
+    # above 8x8 the stand-alone state-only entry points run one board per lane (k_state); the image kernel's answers
+    # (k_lines, ts_tuning(TS_TUNE_STATE_ONLY, 0)) must be the same
+    from tiler_slider_amd import _cabi
+    before = _cabi.lib().ts_tuning(_cabi.TUNE_STATE_ONLY, 0)
+    try:
+        np.testing.assert_array_equal(env.get_valid_moves().cpu().numpy(), (ref.valid_moves()[:, None] >> np.arange(4)) & 1 != 0)
+        np.testing.assert_array_equal(env.valid_move_bits().cpu().numpy(), ref.valid_moves())
+        np.testing.assert_array_equal(env.reward().cpu().numpy(), ref.reward())
+        np.testing.assert_array_equal(env.is_won().cpu().numpy(), ref.won() != 0)
+    finally:
+        _cabi.lib().ts_tuning(_cabi.TUNE_STATE_ONLY, before)
     if not autoreset and max_steps < steps:  # strict mode: every board timed out and was then flagged
         assert (ref.done != 0).all()
 
@@ -1100,3 +1135,113 @@ def test_cached_waves_and_edge_stores_are_speed_only(torch_cuda, oracle, out_of_
                     np.testing.assert_array_equal(info["onehot"].cpu().numpy(), want["onehot"], err_msg=ctx)
     finally:
         L.ts_tuning(_cabi.TUNE_CACHED_EVERY, before)
+
+
+def test_contiguous_allocation_failure_falls_back_cleanly(torch_cuda, oracle, monkeypatch):
+    """a failed hipExtMallocWithFlags leaves HIP's per-thread "last error" set; unread, the library's
+    next launch check (finish_launch -> hipGetLastError) reported it as TS_ERR_HIP although the environment had fallen back to
+    torch's allocator.  Forced here with an allocation no device can satisfy, then a whole environment is built, reset and
+    stepped on the fallback path."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi, vec_env
+    assert vec_env._contiguous_zeros((1 << 50,), torch.uint8, torch.device("cuda", 0)) is None  # 1 PiB: refused
+    # nothing is left behind for the next launch to trip over
+    a = torch.empty(64, dtype=torch.uint8, device="cuda")
+    _cabi.check(_cabi.lib().ts_fill_actions(64, 1, 0, 0, a.data_ptr(), torch.cuda.current_stream().cuda_stream), "ts_fill_actions")
+    # and an environment whose every contiguous allocation fails runs on torch's allocator
+    real = vec_env._ContiguousBuffer.__init__
+
+    def failing(self, nbytes, device):
+        real(self, 1 << 50, device)
+
+    monkeypatch.setattr(vec_env._ContiguousBuffer, "__init__", failing)
+    S, T, K, N = 12, 4, 9, 40_000   # 12x12: 69 MB of observation per buffer
+    monkeypatch.setattr(VecTilerSliderEnv, "_PLACEMENT_MIN_BYTES", 1 << 20)  # so that these buffers count as "large" and ask for contiguous memory
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=12)
+    env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=True, max_steps=20)
+    assert env._outputs_beyond_cache
+    ref = oracle.OracleBatch(S, True, 20, blk, init, tgt)
+    np.testing.assert_array_equal(env.reset().cpu().numpy(), ref.reset())
+    for step in range(3):
+        act = oracle.fill_actions(N, seed=3, step_index=step)
+        obs, _, info = env.step(torch.from_numpy(act))
+        want = ref.step(act)
+        np.testing.assert_array_equal(obs.cpu().numpy(), want["obs"])
+        np.testing.assert_array_equal(info["flags"].cpu().numpy(), want["flags"])
+
+
+def test_observation_ring_takes_the_out_of_cache_forms_and_stays_exact(torch_cuda, oracle):
+    """ABI v6: ts_dims.ring_bytes.  With the cache threshold set between one observation buffer and two, a single-buffered
+    environment launches the cache-resident forms and a double-buffered one the out-of-cache forms (ts_describe_launch on the
+    environments' own dims says so) - and both stay bit-exact, ring slot by ring slot."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    L = _cabi.lib()
+    for S, T, K, N in ((4, 2, 2, 10_000), (7, 12, 6, 3_000), (15, 32, 24, 1_000)):
+        one = 12 * S * S * N
+        before = L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, one + one // 2)
+        try:
+            blk, init, tgt = oracle.generate(S, T, T, K, N, seed=21)
+            ref = oracle.OracleBatch(S, True, 6, blk, init, tgt)
+            single = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=True, max_steps=6, auto_reset=True)
+            ring = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=True, max_steps=6, auto_reset=True, obs_buffers=2)
+            assert single._dims.ring_bytes == 0 and ring._dims.ring_bytes == 2 * one
+            assert _cabi.describe_launch(single._dims)["out_of_cache"] == 0 and _cabi.describe_launch(ring._dims)["out_of_cache"] == 1
+            want0 = ref.reset()
+            np.testing.assert_array_equal(single.reset().cpu().numpy(), want0)
+            np.testing.assert_array_equal(ring.reset().cpu().numpy(), want0)
+            prev = None
+            for step in range(8):
+                act = oracle.fill_actions(N, seed=9, step_index=step)
+                want = ref.step(act, mode=oracle.MODE_AUTORESET)
+                o1, _, i1 = single.step(torch.from_numpy(act))
+                o2, _, i2 = ring.step(torch.from_numpy(act))
+                np.testing.assert_array_equal(o1.cpu().numpy(), want["obs"])
+                np.testing.assert_array_equal(o2.cpu().numpy(), want["obs"])
+                np.testing.assert_array_equal(i2["flags"].cpu().numpy(), want["flags"])
+                if prev is not None:  # the buffer of the step before is still intact
+                    np.testing.assert_array_equal(prev[0].cpu().numpy(), prev[1])
+                prev = (o2, want["obs"])
+        finally:
+            L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, before)
+
+
+@pytest.mark.parametrize("S,T,K,mc,N", [(15, 32, 24, True, 1 << 18), (15, 32, 24, False, 100_003), (9, 4, 9, True, 300_001), (16, 255, 0, True, 5_000),
+                                        (20, 6, 30, True, 70_001), (32, 64, 100, False, 9_999), (32, 255, 200, True, 2_001), (17, 1, 3, False, 65)])
+def test_state_only_kernel_at_scale(torch_cuda, oracle, S, T, K, mc, N):
+    """k_state (one board per lane, above 8x8) at co-residency scale, cfg4's full size among them: the stand-alone entry points and
+    a run of steps of an environment without observation, against the oracle - and the same answers from the image kernel
+    (TS_TUNE_STATE_ONLY = 0)."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    L = _cabi.lib()
+    blk, init, tgt = oracle.generate(S, T, T, K, N, seed=4242 + S)
+    tgt[:, ::5] = init[:, ::5]      # solved at the start
+    if T >= 2:
+        tgt[1, 2::9] = tgt[0, 2::9]  # duplicate targets
+    ref = oracle.OracleBatch(S, mc, 7, blk, init, tgt)
+    bare = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True, obs_dtype=None,
+                                         with_reward=True, with_valid_moves=True)
+    kinds = {_cabi.describe_launch(bare._dims, op, outs)["name"] for op, outs in ((_cabi.OP_OBSERVE, _cabi.OUT_FLAGS), (_cabi.OP_OBSERVE, _cabi.OUT_VALID4))}
+    assert kinds == {"k_state<%s, false>" % ("true" if S > 16 else "false"), "k_state<%s, true>" % ("true" if S > 16 else "false")}
+    ref.reset(), bare.reset()
+
+    def entry_points(ctx):
+        np.testing.assert_array_equal(bare.is_won().cpu().numpy(), ref.won() != 0, err_msg=ctx)
+        np.testing.assert_array_equal(bare.valid_move_bits().cpu().numpy(), ref.valid_moves(), err_msg=ctx)
+        np.testing.assert_array_equal(bare.get_valid_moves().cpu().numpy(), (ref.valid_moves()[:, None] >> np.arange(4)) & 1 != 0, err_msg=ctx)
+        np.testing.assert_array_equal(bare.reward().cpu().numpy(), ref.reward(), err_msg=ctx)
+
+    entry_points("after reset")
+    for step in range(10):
+        act = oracle.fill_actions(N, seed=31, step_index=step)
+        if step == 4:
+            act[::17] = 200
+        want = ref.step(act, mode=oracle.MODE_AUTORESET, obs=False, reward=True, valid=True, valid4=True)
+        _assert_bare_step(bare, torch.from_numpy(act), ref, want, f"S={S} step={step}", extras=True)
+    entry_points("after ten steps")
+    before = L.ts_tuning(_cabi.TUNE_STATE_ONLY, 0)
+    try:
+        entry_points("image kernel")
+    finally:
+        L.ts_tuning(_cabi.TUNE_STATE_ONLY, before)

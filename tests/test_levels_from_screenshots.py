@@ -7,7 +7,11 @@ What these tests establish instead:
     boards drawn by this file in the game's colours parse back exactly; where /root/reference/data exists (build container)
     all 400 screenshots parse with the reference's own asserts holding and equal the committed fixture; the fixture's levels
     satisfy the invariants the kernels rely on;
-  * GPU: every parsed level (grouped by shape) replayed HIP vs oracle for 64 random steps through VecTilerSliderEnv.from_levels.
+  * GPU: every parsed level (grouped by shape) replayed HIP vs oracle for 64 random steps through VecTilerSliderEnv.from_levels;
+  * round 5, an INDEPENDENT property of the parse (tests/level_solver.py): a breadth-first search - over the CPU oracle here, over
+    batched VecTilerSliderEnv frontiers on the GPU - finds every one of the 400 levels solvable, and the least numbers of moves
+    form the staircases of level packs sorted by difficulty (1, 2, 3, 4, 4, 5, 5, 5, 6, ... 15, then the next pack from 1 again).
+    A mis-classified cell would most likely fail one of the two.  Parity with the reference's parser stays unpinned.
 """
 import os
 
@@ -120,6 +124,53 @@ def test_fixture_levels_are_well_formed():
         pack_levels(l.size, [l.blocked_locations], [l.initial_locations], [l.target_locations])  # distinct tiles, none on an obstacle
         assert not set(l.target_locations) & set(l.blocked_locations)
         assert len(set(l.target_locations)) == len(l.target_locations)
+
+
+def _fixture_min_moves():
+    with np.load(os.path.join(GOLDEN_DIR, "levels_from_screenshots.npz")) as z:
+        return dict(zip((str(n) for n in z["names"]), (int(m) for m in z["min_moves"])))
+
+
+def _check_solutions(solved):
+    """Every level solvable, the recorded optimum reproduced, and the packs sorted by it."""
+    import re
+    import level_solver
+    want = _fixture_min_moves()
+    assert len(solved) == 400 and all(v is not None for v in solved.values()), [k for k, v in solved.items() if v is None]
+    assert solved == want
+    for kind, breaks, top in (("multi", [59], [15, 13]), ("single", [3, 99], [3, 15, 11])):
+        names = sorted((n for n in solved if kind in n), key=lambda n: int(re.search(r"(\d+)", n).group(1)))
+        counts = [solved[n] for n in names]
+        # the game's packs: each sorted by the optimal number of moves, starting from one move
+        assert level_solver.staircase_breaks(counts) == breaks, (kind, level_solver.staircase_breaks(counts))
+        starts = [0] + [b + 1 for b in breaks]
+        assert [counts[i] for i in starts] == [1] * len(starts)
+        assert [counts[b] for b in breaks] + [counts[-1]] == top
+        assert all(0 <= counts[i + 1] - counts[i] <= 1 for i in range(len(counts) - 1) if i not in breaks)  # no step is skipped
+
+
+def test_every_parsed_level_is_solvable_and_packs_are_sorted_by_optimal_moves(oracle):
+    import level_solver
+    from tiler_slider_amd.levels import pack_levels
+    won0 = lambda S, mc, blk, init, tgt: oracle.OracleBatch(S, mc, 2**30, blk, init, tgt).won() != 0
+    _check_solutions(level_solver.solve_all(_fixture_levels(), pack_levels, level_solver.oracle_expand(oracle), won0))
+
+
+@pytest.mark.gpu
+def test_breadth_first_search_on_the_gpu_solves_every_parsed_level():
+    """The same search with the HIP path doing the expansions: one VecTilerSliderEnv (no observation) per depth and shape, every
+    (level, state) of the frontier times four moves in one launch."""
+    import torch
+    import level_solver
+    from tiler_slider_amd import VecTilerSliderEnv
+    from tiler_slider_amd.levels import pack_levels
+
+    def won0(S, mc, blk, init, tgt):
+        env = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, obs_dtype=None)
+        env.reset()
+        return env.is_won().cpu().numpy()
+
+    _check_solutions(level_solver.solve_all(_fixture_levels(), pack_levels, level_solver.hip_expand(torch, VecTilerSliderEnv), won0))
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference's screenshots exist in the build container only")

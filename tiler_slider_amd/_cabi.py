@@ -15,24 +15,24 @@ SRC = os.path.join(_PKG, "csrc", "ts_kernels.hip")
 HEADERS = [os.path.join(_PKG, "csrc", "ts_core.h"), os.path.join(ROOT, "include", "tiler_slider.h")]
 LIB_PATH = os.path.join(_PKG, "lib", "libtiler_slider_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 OK, ERR_NULL, ERR_DIMS, ERR_LIMIT, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0x08
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
 MODE_STRICT, MODE_AUTORESET = 0, 1
 TUNE_MULTI_MIN_BOARDS, TUNE_NT_THRESHOLD_BYTES, TUNE_LINES_LANES, TUNE_LINES_BPW, TUNE_EMIT_EDGES, TUNE_XCD_PIECE = 0, 1, 2, 3, 4, 5
-TUNE_DEAL, TUNE_MT_WINDOW, TUNE_SMALL_BPW, TUNE_CACHED_EVERY = 6, 7, 8, 9
+TUNE_DEAL, TUNE_MT_WINDOW, TUNE_SMALL_BPW, TUNE_CACHED_EVERY, TUNE_STATE_ONLY = 6, 7, 8, 9, 10
 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
            "ts_encode_u8", "ts_expand_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions",
-           "ts_lines_words", "ts_prepare", "ts_generate_mt19937", "ts_tuning", "ts_valid_moves4")
+           "ts_lines_words", "ts_prepare", "ts_generate_mt19937", "ts_tuning", "ts_valid_moves4", "ts_describe_launch")
 
 
 class Dims(C.Structure):
     _fields_ = [("n_boards", C.c_int64), ("size", C.c_int32), ("n_tiles", C.c_int32), ("n_targets", C.c_int32),
                 ("multi_color", C.c_int32), ("max_steps", C.c_int32), ("launch_hint", C.c_int32), ("emit_edges", C.c_int32),
-                ("lines_lanes", C.c_int32), ("xcd_piece", C.c_int32)]
+                ("lines_lanes", C.c_int32), ("xcd_piece", C.c_int32), ("ring_bytes", C.c_int64)]
 
 
 class State(C.Structure):
@@ -43,6 +43,32 @@ class State(C.Structure):
 class StepOut(C.Structure):
     _fields_ = [("flags", C.c_void_p), ("obs", C.c_void_p), ("reward", C.c_void_p), ("onehot", C.c_void_p),
                 ("valid", C.c_void_p), ("obs_u8", C.c_void_p), ("valid4", C.c_void_p)]
+
+
+OP_STEP, OP_RESET, OP_OBSERVE = 0, 1, 2
+OUT_OBS, OUT_REWARD, OUT_ONEHOT, OUT_VALID, OUT_OBS_U8, OUT_VALID4, OUT_FLAGS = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
+KERNEL_NAMES = {0: "none", 1: "k_small", 2: "k_multi", 3: "k_deal", 4: "k_lines", 5: "k_state"}
+
+
+class LaunchDesc(C.Structure):
+    """ts_launch_desc of include/tiler_slider.h: what one call of the hot path would launch."""
+    _fields_ = [("kernel", C.c_int32), ("out_of_cache", C.c_int32), ("lanes_per_board", C.c_int32), ("boards_per_lane", C.c_int32),
+                ("boards_per_wave", C.c_int32), ("tiles_per_lane", C.c_int32), ("extras", C.c_int32), ("wide", C.c_int32),
+                ("cached_every", C.c_int32), ("emit_edges", C.c_int32), ("xcd_piece", C.c_int32), ("waves_per_block", C.c_int32),
+                ("blocks_per_cu", C.c_int32), ("lds_bytes_block", C.c_int32), ("lds_bytes_used", C.c_int32), ("reserved", C.c_int32),
+                ("blocks", C.c_int64), ("output_bytes", C.c_int64), ("resident_bytes", C.c_int64), ("name", C.c_char * 64)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d["name"] = self.name.decode()
+        return d
+
+
+def describe_launch(dims, op=OP_STEP, outputs=OUT_OBS):
+    """dict of ts_describe_launch(dims, op, outputs): the launch ts_step / ts_reset / ts_encode ... would make.  No GPU needed."""
+    desc = LaunchDesc()
+    check(lib().ts_describe_launch(C.byref(dims), op, outputs, C.byref(desc)), "ts_describe_launch")
+    return desc.as_dict()
 
 
 class TilerSliderLibraryError(RuntimeError):
@@ -192,6 +218,8 @@ def lib():
     L.ts_onehot_channels.restype = C.c_int32
     L.ts_check_dims.argtypes = [DP]
     L.ts_check_dims.restype = C.c_int32
+    L.ts_describe_launch.argtypes = [DP, C.c_uint32, C.c_uint32, C.POINTER(LaunchDesc)]
+    L.ts_describe_launch.restype = C.c_int32
     for name, args in (("ts_reset", [DP, SP, P, P]),
                        ("ts_step", [DP, SP, P, C.c_uint32, C.POINTER(StepOut), P]),
                        ("ts_valid_moves", [DP, SP, P, P]), ("ts_valid_moves4", [DP, SP, P, P]), ("ts_is_won", [DP, SP, P, P]), ("ts_prepare", [DP, SP, P, P]),

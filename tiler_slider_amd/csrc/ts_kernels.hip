@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstdio>
 
 #include "../../include/tiler_slider.h"
 #include "ts_core.h"
@@ -1702,6 +1703,207 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_state - S 9..32, launches with NO image output (no observation in either form, no one-hot planes): ts_is_won,
+// ts_valid_moves / ts_valid_moves4, ts_reward (multi colour) and the step / reset of an environment that keeps no observation
+// (the actor ranks of the compact multi-GPU hand-off: ts_step_out.obs = NULL).
+//
+// k_lines exists to build and stream an image: it deals a board over 4 .. 32 lanes so that a wave's chunk of output has the
+// right size, and pays for that with table loads, an LDS carve per board, LDS atomics between the lanes of a board and three
+// wave syncs - per FOUR boards at cfg4.  With nothing to stream that is all overhead: 65,536 waves, each a chain of memory round
+// trips (ts_is_won 32 us, ts_valid_moves 37 us at cfg4 for 17 .. 50 MB of traffic: 0.17 - 0.20 of their roofline,
+// profiles/r04_entry_points.md).  Here ONE BOARD PER LANE: every SoA access is coalesced (lane n <-> board n), nothing crosses
+// lanes (no ballot, no shuffle, no sync that matters), a wave carries 64 boards.  The per-board line masks - obstacle rows and
+// columns from the ts_prepare record, tiles along the move's lines, post-move tiles by row - live in LDS as lane-private
+// columns [line][lane]: whatever line a lane asks for, lane L hits bank L & 31, so a wave's access is conflict-free.
+// Tiles are walked in a runtime loop, eight loads in flight.
+// ref: explainrl/environment/state.py:120-186, environment.py:100-171 - the same rules as k_lines, in the same order.
+// ------------------------------------------------------------------------------------------
+template <bool WIDE, bool EXTRAS>
+__global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const uint32_t invS) {
+  using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
+  constexpr int NLN = WIDE ? 32 : 16;
+  constexpr int REC = lines_record_words(WIDE);
+  constexpr int kBatch = 8;
+  auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
+  auto mul_s = [&](int x) -> int { return (int)__umul24((uint32_t)x, (uint32_t)S); };
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
+  const int64_t N = a.N;
+  const int64_t n0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * kWave;
+  if (n0 >= N) return;  // wave-uniform
+  const int64_t n = n0 + lane;
+  const bool live = n < N;
+  const int64_t nl = live ? n : N - 1;  // lanes past the batch compute on the last board and store nothing
+  const int C = S * S;
+  const int T = a.T, Tt = a.Tt;
+  const bool mc = a.mc != 0;
+
+  // lane-private columns: element `line` of this lane's array X is X[line * 64]
+  uint32_t *col = reinterpret_cast<uint32_t *>(smem + (size_t)wave * a.lds_wave_bytes) + lane;
+  uint32_t *lnR = col;                              // S <= 16: Br | Bc << 16 per line; above: Br
+  uint32_t *lnC = col + (WIDE ? NLN * kWave : 0);   //          (the same words)            Bc
+  uint32_t *occ = lnC + NLN * kWave;                // S <= 16: pre-move tiles along the move's lines (low half) | post-move tiles by
+  uint32_t *nrw = occ + (WIDE ? NLN * kWave : 0);   //          row (high half); above: two arrays
+
+  // ---- loads: the record's obstacle lines (and, single colour, its target rows), 16 bytes at a time ----
+  const uint4 *rec = reinterpret_cast<const uint4 *>(a.lines + (size_t)nl * REC);
+  constexpr int kQ = (WIDE ? 64 : 16) / 4;  // quads of obstacle words
+  uint4 q[kQ];
+#pragma unroll
+  for (int i = 0; i < kQ; ++i) q[i] = rec[i];
+  uint32_t action = 0, done_in = 0;
+  int32_t sc = 0;
+  if (a.op == OP_STEP) {  // uniform
+    done_in = a.done[nl];
+    sc = a.step_count[nl];
+    action = a.actions[nl];
+  }
+#pragma unroll
+  for (int i = 0; i < kQ; ++i) {
+    uint32_t *dst = (WIDE && i >= 8 ? lnC + (i - 8) * 4 * kWave : lnR + i * 4 * kWave);
+    dst[0] = q[i].x, dst[kWave] = q[i].y, dst[2 * kWave] = q[i].z, dst[3 * kWave] = q[i].w;
+  }
+#pragma unroll
+  for (int i = 0; i < NLN; ++i) {
+    occ[i * kWave] = 0u;
+    if constexpr (WIDE) nrw[i * kWave] = 0u;
+  }
+
+  int kind;  // 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells
+  uint32_t flags = 0;
+  if (a.op == OP_RESET) {
+    kind = 2;
+  } else if (a.op == OP_OBSERVE) {
+    kind = 1;
+  } else {
+    // environment.py:113-117: done boards are not stepped, action bytes above 3 are refused
+    kind = done_in ? (a.autoreset ? 2 : 1) : (action > 3 ? 1 : 0);
+    flags = done_in ? (a.autoreset ? TS_FLAG_AUTORESET : TS_FLAG_STEPPED_DONE) : (action > 3 ? TS_FLAG_BAD_ACTION : 0u);
+  }
+  const bool slide = kind == 0;
+  const bool vert = (action & 2u) == 0, neg = (action & 1u) == 0;
+  const cell_t *src = reinterpret_cast<const cell_t *>(kind == 2 ? a.init : a.pos) + nl;  // per lane: boards that reset read the level
+  const cell_t *g_tgt = reinterpret_cast<const cell_t *>(a.tgt) + nl;
+  cell_t *pos_out = reinterpret_cast<cell_t *>(a.pos) + nl;
+  wave_sync();
+
+  // ---- pre-move occupancy of the lines the move runs along (state.py:137-144 sorts by them) ----
+  if (__ballot(slide) != 0) {
+    for (int t0 = 0; t0 < T; t0 += kBatch) {
+      int p[kBatch];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) p[k] = (int)src[(int64_t)(t0 + k < T ? t0 + k : 0) * N];
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) {
+        const int pp = min(p[k], C - 1);  // clamp: malformed ids stay in-board
+        const int r = div_s(pp), c = pp - mul_s(r);
+        if (slide && t0 + k < T) atomicOr(&occ[(vert ? c : r) * kWave], 1u << (vert ? r : c));
+      }
+    }
+    wave_sync();
+  }
+
+  // ---- slide (state.py:120-170), flags' ingredients, post-move rows, reward ----
+  const bool need_rows = !mc || (EXTRAS && (a.valid != nullptr || a.valid4 != nullptr));
+  const bool store_pos = live && kind != 1;
+  bool same = true, ordered = true;
+  int rsum = 0;
+  for (int t0 = 0; t0 < T; t0 += kBatch) {
+    int p[kBatch], tg[kBatch];
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      p[k] = (int)src[(int64_t)(t0 + k < T ? t0 + k : 0) * N];
+      tg[k] = Tt > 0 ? (int)g_tgt[(int64_t)(t0 + k < Tt ? t0 + k : 0) * N] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kBatch; ++k) {
+      const int t = t0 + k;
+      if (t < T) {  // uniform
+        const int pp = min(p[k], C - 1), tt = min(tg[k], C - 1);
+        const int r0 = div_s(pp), c0 = pp - mul_s(r0);
+        const int line = vert ? c0 : r0, x0 = vert ? r0 : c0;
+        uint32_t O = occ[line * kWave], B;
+        if constexpr (WIDE) {
+          B = vert ? lnC[line * kWave] : lnR[line * kWave];
+        } else {
+          const uint32_t w = lnR[line * kWave];
+          B = vert ? (w >> 16) : (w & 0xffffu);
+          O &= 0xffffu;
+        }
+        const int x1 = ts::slide_line(x0, B, O, S, neg);
+        const int x = slide ? x1 : x0;
+        const int r = vert ? x : r0, c = vert ? c0 : x;
+        const int qq = mul_s(r) + c;
+        same &= qq == pp;
+        const bool hasG = t < Tt;
+        ordered &= (qq == tt) | !hasG;
+        if (need_rows) atomicOr(&nrw[r * kWave], (WIDE ? 1u : 0x10000u) << c);
+        if (store_pos) pos_out[(int64_t)t * N] = (cell_t)qq;
+        if constexpr (EXTRAS) {
+          if (a.reward && hasG) {  // build-defined Manhattan reward, multi colour (single colour keeps k_lines)
+            const int tr = div_s(tt), tc = tt - mul_s(tr);
+            rsum += abs(r - tr) + abs(c - tc);
+          }
+        }
+      }
+    }
+  }
+  wave_sync();
+  auto tiles_row = [&](int r) -> uint32_t { return WIDE ? nrw[r * kWave] : (nrw[r * kWave] >> 16); };
+  auto obstacles_row = [&](int r) -> uint32_t { return WIDE ? lnR[r * kWave] : (lnR[r * kWave] & 0xffffu); };
+
+  bool won;
+  if (mc) {
+    won = ordered && T == Tt;  // state.py:183-184
+  } else {                     // state.py:185-186: the SETS of tile and target cells are equal - row masks against the record's Tm
+    won = true;
+    const uint32_t *tm = a.lines + (size_t)nl * REC + (WIDE ? 64 : 16);
+    for (int r = 0; r < S; ++r) won &= tiles_row(r) == (WIDE ? tm[r] : (tm[r] & 0xffffu));
+  }
+  if (a.op == OP_OBSERVE && won) flags |= TS_FLAG_IS_WON;
+  if (slide) {
+    if (won) flags |= TS_FLAG_IS_WON | TS_FLAG_SUCCESS;
+    if (same) flags |= TS_FLAG_INVALID_MOVE;
+    sc += 1;
+    if (sc >= a.max_steps) flags |= TS_FLAG_TIMEOUT;
+  }
+  if (live) {
+    if (slide) {
+      a.step_count[n] = sc;
+      a.done[n] = (uint8_t)((flags & (TS_FLAG_IS_WON | TS_FLAG_TIMEOUT)) != 0);
+    } else if (kind == 2) {
+      a.step_count[n] = 0;
+      a.done[n] = 0;
+    }
+    if (a.flags) a.flags[n] = (uint8_t)flags;
+  }
+
+  if constexpr (EXTRAS) {
+    // ---- legality mask of the post-move board (environment.py:149-171): a move changes the board iff some tile has a free
+    //      neighbour cell in its direction (ts_core.h: valid_mask) - row by row on the masks ----
+    if (a.valid || a.valid4) {
+      uint32_t vm = 0;
+      const uint32_t last = 1u << (S - 1);
+      uint32_t above = 0xffffffffu;  // "row -1" is full: nothing moves up out of row 0
+      uint32_t tiles = tiles_row(0), filled = tiles | obstacles_row(0);
+      for (int r = 0; r < S; ++r) {
+        const uint32_t tiles_next = r + 1 < S ? tiles_row(r + 1) : 0u;
+        const uint32_t filled_next = r + 1 < S ? (tiles_next | obstacles_row(r + 1)) : 0xffffffffu;
+        vm |= (tiles & ~above) ? 1u : 0u;                         // UP
+        vm |= (tiles & ~filled_next) ? 2u : 0u;                   // DOWN
+        vm |= (tiles & ~((filled << 1) | 1u)) ? 4u : 0u;          // LEFT: column 0 never moves left
+        vm |= (tiles & ~((filled >> 1) | last)) ? 8u : 0u;        // RIGHT: column S - 1 never moves right
+        above = filled, tiles = tiles_next, filled = filled_next;
+      }
+      if (live && a.valid) a.valid[n] = (uint8_t)vm;
+      if (live && a.valid4) reinterpret_cast<uint32_t *>(a.valid4)[n] = spread_valid(vm);
+    }
+    if (a.reward && live) a.reward[n] = -rsum;
+  }
+}
+
 // ts_prepare: the static tables of k_lines, once per level.  Same lane mapping as k_lines (16 lanes
 // per board, lane j builds line j and j + 16); not a hot path.
 template <bool WIDE>
@@ -2034,13 +2236,14 @@ std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): I
 std::atomic<int64_t> g_mt_window{kMtLongWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
 std::atomic<int64_t> g_cached_every{0};  // ts_tuning(TS_TUNE_CACHED_EVERY): 0 = policy, 1 = never, N >= 2 = every N-th wave of every k_small launch beyond the cache
 std::atomic<int64_t> g_small_bpw{0};  // ts_tuning(TS_TUNE_SMALL_BPW): 0 = policy, 16 / 32 / 64 = boards per wave of k_small's register forms beyond the cache
+std::atomic<int64_t> g_state_only{1};    // ts_tuning(TS_TUNE_STATE_ONLY): 0 = launches without an image output stay on k_lines above 8x8
 std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
 std::atomic<int64_t> g_nt_threshold_bytes{(int64_t)TS_NT_THRESHOLD_MB * 1024 * 1024};  // ts_tuning(TS_TUNE_NT_THRESHOLD_BYTES)
 
 int32_t check_dims(const ts_dims *d) {
   if (!d) return TS_ERR_NULL;
-  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 || d->emit_edges < 0 || d->emit_edges > 4 || d->xcd_piece < 0 || d->xcd_piece > (1 << 20) ||
+  if (d->n_boards < 0 || d->size < 1 || d->n_tiles < 0 || d->n_targets < 0 || d->max_steps < 1 || d->launch_hint < -8 || d->launch_hint > 8 || d->emit_edges < 0 || d->emit_edges > 4 || d->xcd_piece < 0 || d->xcd_piece > (1 << 20) || d->ring_bytes < 0 ||
       (d->lines_lanes != 0 && d->lines_lanes != 4 && d->lines_lanes != 8 && d->lines_lanes != 16 && d->lines_lanes != 32) ||
       (d->multi_color != 0 && d->multi_color != 1))
     return TS_ERR_DIMS;
@@ -2206,6 +2409,65 @@ struct Residency {
   int waves_per_block;  // 0 = keep the kernel's default
   int blocks_per_cu;    // 0 = unbounded
 };
+
+// ------------------------------------------------------------------------------------------------------------------
+// THE LAUNCH POLICY'S MEASURED CONSTANTS, in one place (round 5).  Every row names the log under profiles/ that set it;
+// the functions below (ooc_residency, edge_policy_capped, piece_policy, cached_every_policy, small_boards_per_wave, the
+// lane choice of k_lines) only read this table.  tests/test_launch_policy.py pins what the table yields for every BASELINE
+// config and on both sides of every size cliff, through ts_describe_launch - change a row and that test says which
+// launches moved.  All of it is speed only.  Tuned on physically contiguous output buffers (the host's default beyond
+// 256 MiB).
+// ------------------------------------------------------------------------------------------------------------------
+namespace policy {
+constexpr uint64_t KiB = 1024ull, MiB = 1024ull * 1024ull;
+struct ByChunk { uint64_t min_chunk; int value; };  // first row with chunk >= min_chunk applies
+// Resident one-wave blocks per CU by the bytes a wave streams out in one piece.
+//   k_lines (r04_residency_contiguous.log, blocks per CU round 3 -> round 4, us per 600 MB): 11x11 12 -> 18 (103.7 -> 92.6), 13x13
+//   18 -> 22 (95.7 -> 88.2), 16x16 10 -> 14 (83.7 -> 78.3), 20x20 10 -> 8 (95.2 -> 91.2), 24x24 7 -> 9, 32x32 4 -> 6; cfg4 (10.8 KB) flat at 18
+constexpr ByChunk kLinesBlocksPerCu[] = {{40 * KiB, 6}, {24 * KiB, 9}, {16 * KiB, 8}, {14 * KiB, 10}, {12 * KiB, 14}, {10 * KiB, 18}, {8 * KiB, 22}, {0, 18}};
+//   k_small (same log): cfg2 (25.6 KB per half wave) 2 blocks 247 us, 4: 138, 6: 120, 8: 113; 7x7 14; 4x4 full waves / 6x6 / 8x8
+//   quarter waves 18 (8x8: 87.8 us with 14, 82.8 with 18); 5x5 10 -> 14 (93.1 -> 86.0), 16 from five tiles on; 3x3 and below 18
+constexpr ByChunk kSmallBlocksPerCu[] = {{22 * KiB, 8}, {16 * KiB, 14}, {11 * KiB, 18}, {8 * KiB, 14}, {0, 18}};
+constexpr uint64_t kSmallMidChunk = 8 * KiB;   // the {8 KiB, 14} row reads 16 with more than ...
+constexpr int kSmallMidChunkTiles = 4;         // ... this many tiles
+constexpr int kSmallMidChunkBlocksManyTiles = 16;
+// Write-back edge stores (first / last store instruction of a wave's chunk): r03_emit_edges_ab.log - worth 3-10 % from 8 KB
+// chunks on (cfg2 139 -> 125 us, 12x12 77 -> 73, 6x6 71 -> 67), harmful on short chunks (4x4 half wave 115 -> 194 us)
+constexpr uint64_t kEdgeMinChunk = 8 * KiB;
+// ... and their absolute cap per launch, 1 KiB per edge instruction and chunk (r04_large_batch_edges*.log, r04_knee_probe.log: beyond
+// ~150 MB of cached edge bytes the kernels that read much state per board lose half their rate - cfg4's shape at 1.4 GB 401.8 us
+// with both edges, 214.4 with the last only, 212.0 with none); beyond 1 GiB per launch a little less is tolerated (24x24 at 2.1 GB)
+constexpr uint64_t kEdgeCapBytes = 152 * MiB, kEdgeCapBytesBeyond = 128 * MiB, kEdgeCapSwitch = 1024 * MiB, kEdgeBytesPerSite = 1 * KiB;
+constexpr int kEdgeCapStateBytes = 20;  // k_small forms with fewer bytes of state per board keep both edges at any size (4x4 / 5x5 with two
+                                        // tiles at 1 GB: both 149 / 146 us, one 154 - 166, none 173 / 176; r04_large_batch_edges_small_boards*.log)
+// Block -> board-range mapping: pieces of P one-wave blocks per XCD (r04_contig_sweep.log, r04_piece_by_shape.log; eighths -> best piece:
+// cfg2 122.2 -> 118.4 us with 32, cfg4 113.9 -> 107.7 with 16, 4x4 at 4M boards 133 -> 124.5 with 64)
+constexpr uint32_t kPieceShortChunk = TS_XCD_PIECE_POLICY, kPieceLongChunk = TS_XCD_PIECE_LONG, kPieceDealt = TS_XCD_PIECE_LINES;
+constexpr uint64_t kPieceLongFrom = 8 * KiB;
+// A cached wave in every N of a nontemporal stream (r04_cached_every_nth_wave*.log, r04_cached_every_wide_boards.log,
+// r04_cached_every_validation.log): single-stream launches up to 704 MiB; 3x3 .. 8x8 one lane per board: every 16th (6x6 -7 .. -9 %,
+// 5x5 / 3x3 / 8x8 -1.5 .. -7 %, 4x4 and 7x7 +-0.7 %); boards above 16x16: every 16th up to 512 MiB, every 32nd up to 704 MiB
+// (32x32 / 32 tiles 74.7 -> 68.8 us); 9x9 .. 16x16, k_deal and two-stream launches: none (cfg4 +1.5 % even with every 32nd)
+constexpr uint64_t kCachedMaxBytes = 704 * MiB, kCachedWideDenseMaxBytes = 512 * MiB;
+constexpr uint32_t kCachedEverySmall = 16, kCachedEveryWide = 16, kCachedEveryWideLarge = 32;
+// Boards per wave of k_small's register forms beyond the cache (r04_small_boards_per_wave*.log, r04_big_chunk_probe.log: a wave's
+// chunk of observation should be 9 .. 14 KB - 4x4 full waves 95.5 -> 90.5 us per 600 MB, 7x7 / 8x8 quarter waves 0.80 -> 0.96)
+constexpr uint64_t kSmallChunkMax = 14 * KiB, kSmallChunkMaxBeyond1G = 7 * KiB;  // (r04_learner_side_sweep.log: 8M 4x4 boards full waves 284 us, half 250)
+constexpr uint64_t kSmallFullWavesStateBytes = 640 * MiB;  // state beyond the cache too: full waves (4x4 at 64M boards 3.35 -> 2.57 ms)
+constexpr uint64_t kHugeStream = 1200 * MiB;               // 7x7 / 8x8 beyond it: half waves + eighths (r04_large_batch_probe.log: 0.62 -> 0.88)
+constexpr uint64_t kHugeStreamMinPrimary = 12 * 49;        //   ... "7x7 / 8x8" = from 588 B of observation per board on
+constexpr uint64_t kBeyond1G = 1024 * MiB;                 // up to 6x6 with >= 20 B of state per board: full waves beyond it
+constexpr int kFullWavesStateBytesPerBoard = 20;           //   (r04_large_batch_probe_small_boards.log: 5x5 / 6 tiles at 1.4 GB 308.5 -> 218.5 us)
+constexpr uint64_t kEighthsChunk = 16 * KiB;               // chunks this long of a stream beyond kHugeStream: one eighth of the batch per XCD
+// Lanes per board of k_lines (r03_lines_lanes_ab.log, r04_lines_lanes_sweep*.log, r04_lines_bpw_sweep*.log): 4 lanes up to 10x10 / 4
+// tiles (9x9 96 -> 89 us), 8 up to 13x13 / 16 tiles (11x11 94.0 -> 85.6, 13x13 91.0 -> 82.2), 32 from 20x20 on (20x20 94.5 -> 85.0),
+// else 16; one board per wave from 28x28 with at most 16 tiles (28x28 92.2 -> 79.9, 32x32 / 4 tiles 91.1 -> 81.3)
+constexpr int kLines4MaxS = 10, kLines4MaxT = 4, kLines8MaxS = 13, kLines8MaxT = 16, kLines32MinS = 20, kLinesOneBoardMinS = 28, kLinesOneBoardMaxT = 16;
+constexpr int lookup(const ByChunk *rows, uint64_t chunk) {
+  while (chunk < rows->min_chunk) ++rows;
+  return rows->value;
+}
+}  // namespace policy
 Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy, uint64_t chunk, int tiles) {
 #if defined(TS_RES_ALWAYS)  // experiment: apply the forced residency to cache-resident launches too
   (void)out_of_cache;
@@ -2221,29 +2483,18 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
   // blocks per CU round 3 -> now, us per step of a 600 MB batch): 5x5 10 -> 14 (93.1 -> 86.0), 4x4 14 -> 18 (97.2 -> 95.4),
   // 11x11 12 -> 18 (103.7 -> 92.6), 13x13 18 -> 22 (95.7 -> 88.2), 16x16 10 -> 14 (83.7 -> 78.3), 20x20 10 -> 8 (95.2 -> 91.2),
   // 24x24 7 -> 9, 32x32 4 -> 6; cfg2 (8) and cfg4 (18) are flat around their old values.
-  if (lines_kernel) {
-    if (chunk >= 40u * 1024u) return {1, 6};
-    if (chunk >= 24u * 1024u) return {1, 9};
-    if (chunk >= 16u * 1024u) return {1, 8};
-    if (chunk >= 14u * 1024u) return {1, 10};
-    if (chunk >= 12u * 1024u) return {1, 14};
-    if (chunk >= 10u * 1024u) return {1, 18};   // cfg4
-    if (chunk >= 8u * 1024u) return {1, 22};
-    return {1, 18};
-  }
-  // k_small, half waves (32 boards per wave, see small_boards_per_wave): `chunk` is the half wave's output
-  if (chunk >= 22u * 1024u) return {1, 8};                     // cfg2 (25.6 KB): 2 blocks per CU 247 us, 4: 138, 6: 120, 8: 113
-  if (chunk >= 16u * 1024u) return {1, 14};                    // 7x7
-  if (chunk >= 11u * 1024u) return {1, 18};                    // 4x4 (full waves), 6x6, 8x8 (quarter waves: 87.8 us with 14, 82.8 with 18)
-  if (chunk >= 8u * 1024u) return {1, tiles <= 4 ? 14 : 16};   // 5x5, 7x7
-  return {1, 18};                                              // 3x3 and below
+  if (lines_kernel) return {1, policy::lookup(policy::kLinesBlocksPerCu, chunk)};
+  // k_small, partial waves (see small_boards_per_wave): `chunk` is what the wave's live lanes write
+  int blocks = policy::lookup(policy::kSmallBlocksPerCu, chunk);
+  if (chunk >= policy::kSmallMidChunk && chunk < 11u * policy::KiB && tiles > policy::kSmallMidChunkTiles) blocks = policy::kSmallMidChunkBlocksManyTiles;
+  return {1, blocks};
 }
 
 // Which store instructions of a wave's chunk go out as write-back stores instead of nontemporal ones (KArgs.emit_edges):
 // the first and the last one (3) once a chunk is long enough that two instructions are a small part of it - worth 3-10 %
 // from 6x6 up (cfg2 139 -> 125 us, 12x12 77 -> 73, 6x6 71 -> 67, 9x9 83.5 -> 79) -, none for short chunks (a 4x4 half
 // wave has six store instructions: 115 -> 194 us with two of them write-back).  profiles/r03_emit_edges_ab.log
-uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= 8u * 1024u ? 3u : 0u; }
+uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= policy::kEdgeMinChunk ? 3u : 0u; }
 // The edge stores are a CACHED share of the stream - 1 KiB per edge instruction and chunk - and that share must stay small in
 // absolute terms for the kernels that also read a lot of state per board (k_lines: line tables and up to 255 tiles; k_deal): from
 // ~150 MB of edge stores per launch on they fall to half their rate (round 4, profiles/r04_large_batch_edges.log, r04_knee_probe.log;
@@ -2257,9 +2508,9 @@ uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= 8u * 1024u ? 3u :
 // Beyond 1 GiB per launch a little less is tolerated (24x24 at 2.1 GB with one edge, 148 MiB: 425 us; with none: 344).
 uint32_t edge_policy_capped(uint64_t obs_chunk, uint64_t edge_instruction_sites, bool keep_first) {
   uint32_t e = edge_policy(obs_chunk);
-  const uint64_t kCap = (obs_chunk * edge_instruction_sites > (1ull << 30) ? 128ull : 152ull) << 20;
-  if (e == 3u && 2u * 1024u * edge_instruction_sites > kCap) e = keep_first ? 1u : 2u;  // one edge instruction only
-  if (e != 0u && e != 3u && 1024u * edge_instruction_sites > kCap) e = 0u;
+  const uint64_t kCap = obs_chunk * edge_instruction_sites > policy::kEdgeCapSwitch ? policy::kEdgeCapBytesBeyond : policy::kEdgeCapBytes;
+  if (e == 3u && 2u * policy::kEdgeBytesPerSite * edge_instruction_sites > kCap) e = keep_first ? 1u : 2u;  // one edge instruction only
+  if (e != 0u && e != 3u && policy::kEdgeBytesPerSite * edge_instruction_sites > kCap) e = 0u;
   return e;
 }
 
@@ -2275,8 +2526,8 @@ uint32_t edge_policy_capped(uint64_t obs_chunk, uint64_t edge_instruction_sites,
 // approaches eighths again.
 uint32_t piece_policy(bool lines_kernel, uint64_t chunk) {
 #if TS_XCD_PIECE_POLICY >= 0
-  if (lines_kernel) return TS_XCD_PIECE_LINES;
-  return chunk < 8u * 1024u ? TS_XCD_PIECE_POLICY : TS_XCD_PIECE_LONG;
+  if (lines_kernel) return policy::kPieceDealt;
+  return chunk < policy::kPieceLongFrom ? policy::kPieceShortChunk : policy::kPieceLongChunk;
 #else
   return 0u;
 #endif
@@ -2295,13 +2546,13 @@ uint32_t cached_every_policy(int S, uint64_t output_bytes, bool two_streams) {
   const int64_t forced = g_cached_every.load(std::memory_order_relaxed);
   if (forced == 1) return 0u;
   if (forced >= 2 && forced <= 0x7fffffff) return (uint32_t)forced;
-  if (two_streams || output_bytes > (704ull << 20)) return 0u;  // (measured up to 700 / 720 MB; at 800 MB 7x7 +1.9 %, the 4M 4x4 sibling +2.7 % in one run)
-  if (S >= 3 && S <= 8) return 16u;
+  if (two_streams || output_bytes > policy::kCachedMaxBytes) return 0u;  // (measured up to 700 / 720 MB; at 800 MB 7x7 +1.9 %, the 4M 4x4 sibling +2.7 % in one run)
+  if (S >= 3 && S <= 8) return policy::kCachedEverySmall;
   // Boards above 16x16 (k_lines, 16-bit cells; r04_cached_every_wide_boards.log, thirteen shapes from 17x17 to 32x32): every 16th
   // wave up to 512 MiB (-0.3 .. -8 %; 32x32 with 32 tiles 74.7 -> 68.8 us, 24x24 with 4 tiles 72.8 -> 66.8), every 32nd up to 704
   // MiB (-0.2 .. -4.8 %, one shape +1.3 %; every 16th there: +6 % at 20x20 with 10 tiles).  9x9 .. 16x16 go either way (cfg4 +1.5 %
   // even with every 32nd wave, 11x11 .. 13x13 -2.5 %): all-nontemporal.
-  if (S > 16) return output_bytes <= (512ull << 20) ? 16u : 32u;
+  if (S > 16) return output_bytes <= policy::kCachedWideDenseMaxBytes ? policy::kCachedEveryWide : policy::kCachedEveryWideLarge;
   return 0u;
 }
 
@@ -2313,7 +2564,7 @@ uint32_t cached_every_policy(int S, uint64_t output_bytes, bool two_streams) {
 // half waves (9.6 / 13.8 KB), 7x7 and 8x8 QUARTER waves (9.4 / 12.3 KB: 7x7 98.9 -> 83.2, 8x8 with 4 tiles 95.5 -> 82.8,
 // with 8 tiles 101.8 -> 82.8: 0.80 -> 0.96 of the HBM roofline).  `primary`: bytes per board of the launch's first large
 // stream (float32 observation, else uint8 observation, else one-hot planes).
-constexpr uint64_t kHugeStreamBytes = 1200ull << 20;
+constexpr uint64_t kHugeStreamBytes = policy::kHugeStream;
 int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primary, uint64_t state_bytes, uint64_t n_boards) {
 #if TS_SMALL_OOC_BPW > 0
   return (out_of_cache && register_path) ? TS_SMALL_OOC_BPW : kWave;
@@ -2323,7 +2574,7 @@ int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primar
   // Once the STATE of the batch no longer fits the Infinity Cache either (tens of millions of boards) a partial wave's short
   // pieces of every state row cost more than its shorter chunk wins: 4x4 at 64M boards 3.35 ms with half waves, 2.57 with full
   // ones (at 16M boards, 300 MB of state, half waves still win: 592 vs 722 us).
-  if (state_bytes > (640ull << 20)) return kWave;
+  if (state_bytes > policy::kSmallFullWavesStateBytes) return kWave;
   if (const int64_t forced = g_small_bpw.load(std::memory_order_relaxed); forced == 16 || forced == 32 || forced == 64) return (int)forced;
   // (Streams beyond 1 GiB - cfg3's learner re-encoding 8,388,608 gathered 4x4 boards: 1.6 GB - want the shorter chunk again:
   // full waves 284 us, half waves 250, while at 2M / 4M boards full waves win 56 / 113 against 64 / 127:
@@ -2332,13 +2583,13 @@ int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primar
   // the roofline, half waves with one contiguous eighth per XCD (piece_policy) hold 0.87 - 0.88: 7x7 at 1.3 / 1.7 GB 248.6 -> 196.6 /
   // 365.4 -> 256.6 us, 8x8 203.9 -> 195.5 / 296.9 -> 252.0 (at 1.0 GB quarter waves still win: 150 against 165;
   // profiles/r04_large_batch_probe.log).
-  if (primary >= 12u * 49u && primary * n_boards > kHugeStreamBytes) return 32;
+  if (primary >= policy::kHugeStreamMinPrimary && primary * n_boards > kHugeStreamBytes) return 32;
   // Boards up to 6x6 with 20 bytes of state per board and more (six tiles, say) want FULL waves beyond 1 GiB - fewer, wider state
   // accesses - where the two-tile forms want shorter chunks: 5x5 / 6 tiles at 1.4 GB 308.5 us with quarter waves, 218.1 with full
   // ones (0.63 -> 0.89), 4x4 / 6 tiles at 2.1 GB 522 -> 355, 6x6 / 6 tiles at 1.4 GB 248 -> 220, 6x6 / 3 tiles 225.5 -> 208.8
   // (profiles/r04_large_batch_probe_small_boards.log).
-  if (primary * n_boards > (1ull << 30) && state_bytes >= 20u * n_boards) return kWave;
-  const uint64_t limit = primary * n_boards > (1ull << 30) ? 7u * 1024u : 14u * 1024u;
+  if (primary * n_boards > policy::kBeyond1G && state_bytes >= (uint64_t)policy::kFullWavesStateBytesPerBoard * n_boards) return kWave;
+  const uint64_t limit = primary * n_boards > policy::kBeyond1G ? policy::kSmallChunkMaxBeyond1G : policy::kSmallChunkMax;
   for (int bpw = kWave; bpw > 16; bpw >>= 1)
     if (primary * (uint64_t)bpw <= limit) return bpw;
   return 16;
@@ -2361,8 +2612,25 @@ int32_t finish_launch() {
   return TS_OK;
 }
 
-// The one launch path behind ts_reset / ts_step / ts_encode / ts_valid_moves / ...
-int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
+using LinesKernel = void (*)(const KArgs, const int, const uint32_t);
+
+// What one call of the hot path launches: kernel, grid, LDS request and the policy fields of KArgs - everything launch() decides,
+// computed without touching the device (plan_launch), so that ts_describe_launch can report it and a CPU test can pin it.
+struct LaunchPlan {
+  KArgs a;
+  SmallKernel small = nullptr;   // k_small / k_multi / k_deal
+  LinesKernel lines = nullptr;   // k_lines
+  int S = 0;
+  uint32_t inv_s = 0;
+  uint32_t blocks = 0, threads = 0;
+  size_t lds_request = 0, lds_used = 0;
+  // description (ts_launch_desc)
+  int32_t family = 0, lanes_per_board = 0, boards_per_lane = 1, tiles_per_lane = 0, extras = 0, wide = 0, waves_per_block = 0, blocks_per_cu = 0;
+  uint64_t output_bytes = 0, resident_bytes = 0;
+};
+
+// The one launch path behind ts_reset / ts_step / ts_encode / ts_valid_moves / ...: plan_launch decides, launch() launches.
+int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &plan) {
   const int S = d->size, C = S * S, T = d->n_tiles, Tt = d->n_targets;
   if (d->n_boards == 0) return TS_OK;  // nothing to do; an empty batch may carry NULL buffers
   if (!st->blk) return TS_ERR_NULL;
@@ -2386,8 +2654,13 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
   a.onehot_ch = onehot_channels(d);
   {
     const uint64_t per_board = (a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull);
-    a.nt = per_board * (uint64_t)d->n_boards > (uint64_t)g_nt_threshold_bytes.load(std::memory_order_relaxed) ? 1u : 0u;
+    plan.output_bytes = per_board * (uint64_t)d->n_boards;
+    // classified by what successive launches keep rewriting (ts_dims.ring_bytes: an observation ring of k buffers), when the
+    // caller says so: a launch with no large output stays what it is
+    plan.resident_bytes = plan.output_bytes && (uint64_t)d->ring_bytes > plan.output_bytes ? (uint64_t)d->ring_bytes : plan.output_bytes;
+    a.nt = plan.resident_bytes > (uint64_t)g_nt_threshold_bytes.load(std::memory_order_relaxed) ? 1u : 0u;
   }
+  plan.S = S;
   if (a.nt) {
     const int64_t piece = g_xcd_piece.load(std::memory_order_relaxed);
     a.xcd_piece = d->xcd_piece == 1 ? 0u : d->xcd_piece > 1 ? (uint32_t)d->xcd_piece
@@ -2395,7 +2668,6 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const int64_t forced = g_emit_edges.load(std::memory_order_relaxed);
     a.emit_edges = d->emit_edges > 0 ? (uint32_t)(d->emit_edges - 1) : forced >= 0 && forced <= 3 ? (uint32_t)forced : 0xffu;  // 0xff: by shape, below
   }
-  hipStream_t hs = (hipStream_t)stream;
 
   if (S <= 8) {
     const int tfix = (T == Tt && T >= 1 && T <= TS_MAX_TFIX && T <= C) ? T : 0;  // cells in registers
@@ -2413,8 +2685,12 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
       while (waves > 1 && (size_t)waves * a.lds_wave_bytes > kMaxBlockLds) waves >>= 1;
       const int64_t boards_per_block = (int64_t)waves * a.bpw;
       const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
-      hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), (size_t)waves * a.lds_wave_bytes, hs, a);
-      return finish_launch();
+      plan.small = k, plan.blocks = (uint32_t)blocks, plan.threads = (uint32_t)(waves * kWave);
+      plan.lds_request = plan.lds_used = (size_t)waves * a.lds_wave_bytes;
+      plan.family = TS_KERNEL_MULTI, plan.lanes_per_board = 1, plan.boards_per_lane = TS_MULTI_G, plan.tiles_per_lane = tfix;
+      plan.extras = extras, plan.waves_per_block = waves;
+      plan.a = a;
+      return TS_OK;
     }
 #endif
     const int maxT = T > Tt ? T : Tt;
@@ -2454,8 +2730,12 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
         const int64_t boards_per_block = (int64_t)waves * bpw;
         const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
         if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a);
-        return finish_launch();
+        plan.small = k, plan.blocks = (uint32_t)blocks, plan.threads = (uint32_t)(waves * kWave);
+        plan.lds_request = lds_request, plan.lds_used = (size_t)waves * a.lds_wave_bytes;
+        plan.family = TS_KERNEL_DEAL, plan.lanes_per_board = lanes, plan.tiles_per_lane = tpl, plan.extras = extras;
+        plan.waves_per_block = waves, plan.blocks_per_cu = res.blocks_per_cu;
+        plan.a = a;
+        return TS_OK;
       }
     }
     const bool need_masks = a.onehot && !a.oh_boards;
@@ -2470,10 +2750,10 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     if (a.emit_edges == 0xffu) {
       const uint64_t chunk = (uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch);
       const uint64_t sites = ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw * ((a.obs && a.onehot) ? 2u : 1u);
-      a.emit_edges = (T + Tt + 4 * ((C + 31) / 32) + 7 >= 20) ? edge_policy_capped(chunk, sites, true) : edge_policy(chunk);
+      a.emit_edges = (T + Tt + 4 * ((C + 31) / 32) + 7 >= policy::kEdgeCapStateBytes) ? edge_policy_capped(chunk, sites, true) : edge_policy(chunk);
     }
     if (a.xcd_piece == 0xffffffffu)  // (streams beyond ~1.2 GiB in chunks of 16 KB and more - 7x7 / 8x8 half waves: eighths, see small_boards_per_wave)
-      a.xcd_piece = ((uint64_t)a.bpw * out_per_board >= 16u * 1024u && out_per_board * (uint64_t)d->n_boards > kHugeStreamBytes) ? 0u : piece_policy(false, (uint64_t)a.bpw * out_per_board);
+      a.xcd_piece = ((uint64_t)a.bpw * out_per_board >= policy::kEighthsChunk && out_per_board * (uint64_t)d->n_boards > kHugeStreamBytes) ? 0u : piece_policy(false, (uint64_t)a.bpw * out_per_board);
     a.cached_every = a.nt ? cached_every_policy(S, out_per_board * (uint64_t)d->n_boards, a.onehot != nullptr) : 0u;
     apply_launch_hint(res, d->launch_hint);
     int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
@@ -2487,12 +2767,31 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const bool extras = a.valid || a.valid4 || a.reward || a.onehot;
     SmallKernel k = extras ? (a.nt ? small_kernel<true, true>(S, tfix) : small_kernel<true, false>(S, tfix))
                            : (a.nt ? small_kernel<false, true>(S, tfix) : small_kernel<false, false>(S, tfix));
-#if TS_SET_LDS_ATTR
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_request);
-#endif
-    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a);
+    plan.small = k, plan.blocks = (uint32_t)blocks, plan.threads = (uint32_t)(waves * kWave);
+    plan.lds_request = lds_request, plan.lds_used = (size_t)waves * a.lds_wave_bytes;
+    plan.family = TS_KERNEL_SMALL, plan.lanes_per_board = 1, plan.tiles_per_lane = tfix, plan.extras = extras;
+    plan.waves_per_block = waves, plan.blocks_per_cu = res.blocks_per_cu;
   } else {
     if (!st->lines) return TS_ERR_NULL;  // boards above 8x8 need the per-level tables of ts_prepare
+    if (!a.obs && !a.obs_u8 && !a.onehot && !(a.reward && !d->multi_color) && g_state_only.load(std::memory_order_relaxed) != 0) {
+      // no image to build: one board per lane (k_state).  (The single-colour reward - the nearest target of every tile - stays
+      // with k_lines, which stages a board's target cells in LDS.)
+      const bool wide = S > 16, extras = a.valid || a.valid4 || a.reward;
+      a.lines = st->lines;
+      a.bpw = kWave;
+      a.nt = 0u;
+      a.lds_wave_bytes = (uint32_t)((wide ? 4 : 2) * (wide ? 32 : 16) * kWave * 4);  // 8 KiB, 32 KiB above 16x16
+      const int waves = wide ? 2 : 4;
+      const int64_t blocks = (d->n_boards + (int64_t)waves * kWave - 1) / ((int64_t)waves * kWave);
+      if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
+      plan.lines = wide ? (extras ? k_state<true, true> : k_state<true, false>) : (extras ? k_state<false, true> : k_state<false, false>);
+      plan.inv_s = (uint32_t)((65536 + S - 1) / S);
+      plan.blocks = (uint32_t)blocks, plan.threads = (uint32_t)(waves * kWave);
+      plan.lds_request = plan.lds_used = (size_t)waves * a.lds_wave_bytes;
+      plan.family = TS_KERNEL_STATE, plan.lanes_per_board = 1, plan.extras = extras, plan.wide = wide, plan.waves_per_block = waves;
+      plan.a = a;
+      return TS_OK;
+    }
     // step / reset / encode (+ legality mask, reward, one-hot) with the level's precomputed line masks: k_lines
     const bool wide = S > 16;
     a.lines = st->lines;
@@ -2507,9 +2806,9 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     // (19 .. 49 KB) is what limits the launch - the store-only probe writes private 49,152-B chunks at 5.8 TB/s at best and
     // 12,288-B chunks at 7.5 (profiles/r04_big_chunk_probe.log) - so a board gets 32 lanes, one line each, and a wave two boards.
     int lpb = 16;
-    if (S <= 13 && maxT <= 16) lpb = 8;
-    if (S <= 10 && maxT <= 4) lpb = 4;
-    if (S >= 20) lpb = 32;
+    if (S <= policy::kLines8MaxS && maxT <= policy::kLines8MaxT) lpb = 8;
+    if (S <= policy::kLines4MaxS && maxT <= policy::kLines4MaxT) lpb = 4;
+    if (S >= policy::kLines32MinS) lpb = 32;
     if (const int64_t forced = g_lines_lanes.load(std::memory_order_relaxed); forced == 4 || forced == 8 || forced == 16 || forced == 32) lpb = (int)forced;
     if (d->lines_lanes >= 4) lpb = d->lines_lanes;
     if (lpb == 4 && wide) lpb = 8;
@@ -2531,7 +2830,7 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     // stream the image out with the others) - a wave's chunk is then 9.4 .. 12.3 KB instead of 18.8 .. 24.6: 28x28 / 8 tiles
     // 92.2 -> 79.9 us, 32x32 / 4 tiles 91.1 -> 81.3; with 32 tiles the slide's idle lanes cost what the shorter chunk wins
     // (87.8 -> 91.4: stays at two).  profiles/r04_lines_bpw_sweep_32lanes.log
-    if (a.nt && lpb == 32 && S >= 28 && maxT <= 16) a.bpw = 1;  // (S is even here: 12 * C is a multiple of 16)
+    if (a.nt && lpb == 32 && S >= policy::kLinesOneBoardMinS && maxT <= policy::kLinesOneBoardMaxT) a.bpw = 1;  // (S is even here: 12 * C is a multiple of 16)
     // (a wave's chunk of float32 output must start on a 16-byte boundary: 12 * C * bpw % 16 == 0)
     if (const int64_t forced = g_lines_bpw.load(std::memory_order_relaxed); forced >= 1 && forced <= bpw_max && (3 * C * forced) % 4 == 0) a.bpw = (uint32_t)forced;
     Residency res = ooc_residency(a.nt != 0, true, false,
@@ -2552,7 +2851,6 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     const int64_t blocks = (d->n_boards + boards_per_block - 1) / boards_per_block;
     if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
     const uint32_t inv_s = (uint32_t)((65536 + S - 1) / S);
-    using LinesKernel = void (*)(const KArgs, const int, const uint32_t);
     LinesKernel k = nullptr;
     auto pick = [&](auto lpb_c, auto tpl_c) -> LinesKernel {
       constexpr int LPBC = decltype(lpb_c)::value, TPLC = decltype(tpl_c)::value;
@@ -2584,7 +2882,27 @@ int32_t launch(const ts_dims *d, const ts_state *st, KArgs a, void *stream) {
     } else {
       k = tpl == 1 ? pick(integral_constant<int, 4>{}, integral_constant<int, 1>{}) : pick(integral_constant<int, 4>{}, integral_constant<int, 2>{});
     }
-    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(waves * kWave), lds_request, hs, a, S, inv_s);
+    plan.lines = k, plan.inv_s = inv_s, plan.blocks = (uint32_t)blocks, plan.threads = (uint32_t)(waves * kWave);
+    plan.lds_request = lds_request, plan.lds_used = (size_t)waves * a.lds_wave_bytes;
+    plan.family = TS_KERNEL_LINES, plan.lanes_per_board = wide && lpb < 8 ? 8 : lpb, plan.tiles_per_lane = lpb == 32 && tpl > 8 ? 8 : tpl > 16 ? 16 : tpl;
+    plan.extras = lines_extras, plan.wide = wide, plan.waves_per_block = waves, plan.blocks_per_cu = res.blocks_per_cu;
+  }
+  plan.a = a;
+  return TS_OK;
+}
+
+int32_t launch(const ts_dims *d, const ts_state *st, const KArgs &a, void *stream) {
+  LaunchPlan plan;
+  const int32_t rc = plan_launch(d, st, a, plan);
+  if (rc != TS_OK || plan.blocks == 0) return rc;
+  hipStream_t hs = (hipStream_t)stream;
+  if (plan.lines) {
+    hipLaunchKernelGGL(plan.lines, dim3(plan.blocks), dim3(plan.threads), plan.lds_request, hs, plan.a, plan.S, plan.inv_s);
+  } else {
+#if TS_SET_LDS_ATTR
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(plan.small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_request);
+#endif
+    hipLaunchKernelGGL(plan.small, dim3(plan.blocks), dim3(plan.threads), plan.lds_request, hs, plan.a);
   }
   return finish_launch();
 }
@@ -2758,6 +3076,63 @@ int32_t ts_reward(const ts_dims *dims, const ts_state *st, int32_t *reward, void
   return launch(dims, st, a, stream);
 }
 
+int32_t ts_describe_launch(const ts_dims *dims, uint32_t op, uint32_t outputs_mask, ts_launch_desc *desc) {
+  const int32_t rc = check_dims(dims);
+  if (rc) return rc;
+  if (!desc) return TS_ERR_NULL;
+  if (op > TS_OP_OBSERVE || (outputs_mask & ~0x7fu)) return TS_ERR_ARG;
+  *desc = ts_launch_desc{};
+  desc->xcd_piece = -1;
+  // stand-ins for the caller's buffers: non-NULL, aligned for every kernel form (nothing is dereferenced or launched)
+  void *const buf = reinterpret_cast<void *>(uintptr_t{1} << 20);
+  ts_state st = {buf, buf, buf, static_cast<const uint32_t *>(buf), static_cast<int32_t *>(buf), static_cast<uint8_t *>(buf),
+                 static_cast<const uint32_t *>(buf)};
+  KArgs a = {};
+  a.op = op;
+  a.actions = op == TS_OP_STEP ? static_cast<const uint8_t *>(buf) : nullptr;
+  a.flags = (outputs_mask & TS_OUT_FLAGS) || op == TS_OP_STEP ? static_cast<uint8_t *>(buf) : nullptr;
+  a.obs = (outputs_mask & TS_OUT_OBS) ? static_cast<float *>(buf) : nullptr;
+  a.reward = (outputs_mask & TS_OUT_REWARD) ? static_cast<int32_t *>(buf) : nullptr;
+  a.onehot = (outputs_mask & TS_OUT_ONEHOT) ? static_cast<float *>(buf) : nullptr;
+  a.valid = (outputs_mask & TS_OUT_VALID) ? static_cast<uint8_t *>(buf) : nullptr;
+  a.obs_u8 = (outputs_mask & TS_OUT_OBS_U8) ? static_cast<uint8_t *>(buf) : nullptr;
+  a.valid4 = (outputs_mask & TS_OUT_VALID4) ? static_cast<uint8_t *>(buf) : nullptr;
+  LaunchPlan plan;
+  const int32_t prc = plan_launch(dims, &st, a, plan);
+  if (prc != TS_OK) return prc;
+  if (plan.blocks == 0) return TS_OK;  // empty batch: TS_KERNEL_NONE
+  const KArgs &k = plan.a;
+  desc->kernel = plan.family;
+  desc->out_of_cache = (int32_t)k.nt;
+  desc->lanes_per_board = plan.lanes_per_board;
+  desc->boards_per_lane = plan.boards_per_lane;
+  desc->boards_per_wave = (int32_t)k.bpw;
+  desc->tiles_per_lane = plan.tiles_per_lane;
+  desc->extras = plan.extras;
+  desc->wide = plan.wide;
+  desc->cached_every = (int32_t)k.cached_every;
+  desc->emit_edges = k.nt ? (int32_t)k.emit_edges : 0;
+  desc->xcd_piece = k.nt ? (int32_t)k.xcd_piece : -1;
+  desc->waves_per_block = plan.waves_per_block;
+  desc->blocks_per_cu = plan.blocks_per_cu;
+  desc->lds_bytes_block = (int32_t)plan.lds_request;
+  desc->lds_bytes_used = (int32_t)plan.lds_used;
+  desc->blocks = plan.blocks;
+  desc->output_bytes = (int64_t)plan.output_bytes;
+  desc->resident_bytes = (int64_t)plan.resident_bytes;
+  const char *tf[2] = {"false", "true"};
+  const int S = dims->size;
+  switch (plan.family) {
+    case TS_KERNEL_SMALL: snprintf(desc->name, sizeof desc->name, "k_small<%d, %d, %s, %s>", S, plan.tiles_per_lane, tf[plan.extras], tf[k.nt]); break;
+    case TS_KERNEL_MULTI: snprintf(desc->name, sizeof desc->name, "k_multi<%d, %d, %s, %d>", S, plan.tiles_per_lane, tf[plan.extras], plan.boards_per_lane); break;
+    case TS_KERNEL_DEAL: snprintf(desc->name, sizeof desc->name, "k_deal<%d, %d, %d, %s, %s>", S, plan.lanes_per_board, plan.tiles_per_lane, tf[plan.extras], tf[k.nt]); break;
+    case TS_KERNEL_LINES: snprintf(desc->name, sizeof desc->name, "k_lines<%s, %d, %d, %s, %s>", tf[plan.wide], plan.lanes_per_board, plan.tiles_per_lane, tf[k.nt], tf[plan.extras]); break;
+    case TS_KERNEL_STATE: snprintf(desc->name, sizeof desc->name, "k_state<%s, %s>", tf[plan.wide], tf[plan.extras]); break;
+    default: break;
+  }
+  return TS_OK;
+}
+
 int64_t ts_tuning(int32_t key, int64_t value) {
   std::atomic<int64_t> *knob = key == TS_TUNE_MULTI_MIN_BOARDS ? &g_multi_min_boards
                                : key == TS_TUNE_NT_THRESHOLD_BYTES ? &g_nt_threshold_bytes
@@ -2768,7 +3143,8 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_DEAL ? &g_deal_enabled
                                : key == TS_TUNE_MT_WINDOW ? &g_mt_window
                                : key == TS_TUNE_SMALL_BPW ? &g_small_bpw
-                               : key == TS_TUNE_CACHED_EVERY ? &g_cached_every : nullptr;
+                               : key == TS_TUNE_CACHED_EVERY ? &g_cached_every
+                               : key == TS_TUNE_STATE_ONLY ? &g_state_only : nullptr;
   if (!knob) return -1;
   if (key == TS_TUNE_MT_WINDOW && value > kMtLongWindow) value = kMtLongWindow;  // output 623 wraps around to twisted word 0
   return value >= 0 ? knob->exchange(value) : knob->load();

@@ -2,7 +2,7 @@
 
 Boards are independent (nothing in the reference's state.py / environment.py reads another
 board), so rank g simply owns boards [g*N/G, (g+1)*N/G) and generates them from
-(seed, global board index).  The only collective is the hand-off of observations to a single
+(seed, global board index).  The only collective is the hand-off of a step's results to a single
 learner (BASELINE.json north_star: "RCCL all-gather over xGMI only to reassemble
 observations"), in three forms:
 
@@ -10,10 +10,25 @@ observations"), in three forms:
   gather_compact_and_encode()  all-gather of the cell ids (T cells per board), then the learner
                                re-encodes ALL boards with one ts_encode launch — ~64x less xGMI
                                traffic at 4x4, the level tables (obstacles, targets, line masks)
-                               having been gathered once, at construction;
+                               having been gathered once, at construction.  The actor ranks need no
+                               observation at all: build them with obs_dtype=None (their step then
+                               writes 22 MB instead of 223 MB at 1M 4x4 boards);
   gather_u8_and_expand()       for environments built with obs_dtype="uint8": all-gather of the
                                byte observations (3*S*S B per board, 4x less than float32), then
                                one ts_expand_u8 launch on the learner.  No level tables needed.
+
+What the reference's step() returns is (obs, done, info) (environment.py:126-143), and a learner cannot tell a terminal
+transition from a live one by the observation alone.  So EVERY form also hands over the step's flag byte per board (is_won,
+invalid_move, success, timeout, ... - include/tiler_slider.h TS_FLAG_*; `done` follows from it), the int32 Manhattan reward when
+the environment computes one, and on request the step counters: `handle.info` / `gatherer.info` after wait() - a dict with
+`flags`, `done`, `is_won`, `invalid_move`, `success`, `timeout` (+ `reward`, `step_count`).  In the compact form they travel in
+the same message as the cell ids (one collective per step); the two observation forms send them as a second, small collective
+behind the observations (1 B per board, 5 with a reward).
+
+`root`: None (default) = all-gather, every rank ends up with every board (what north_star names).  root = r: a gather to rank r
+only (torch.distributed.gather: batched send / recv on RCCL) - with ONE learner that is all the step needs, and the other ranks'
+HBM is spared the incoming copies (at cfg3, float32 form: 1.5 GiB of writes per step into every actor GPU for a 30-us step).
+On the other ranks wait() returns None.
 
 Every form takes `async_op=True` and then returns a handle at once: the collective runs on the
 backend's own stream (RCCL's) while the caller launches the next step(); `handle.wait()` makes
@@ -23,9 +38,9 @@ What the collective reads while the next step runs (the buffers that are double-
   * observations (float32 / uint8 forms): the environment's own observation ring — build it with
     `obs_buffers=2`, then step k+1 writes the other buffer while gather k reads buffer k % 2
     (async gathers of a single-buffered environment are refused);
-  * cell ids (compact form): `pos` is single-buffered state that step k+1 rewrites in place, so
-    every gather first SNAPSHOTS it, stream-ordered behind step k, into one of two send slots
-    (T bytes per board: 2 MiB at 1M 4x4 boards) and the collective reads the slot.
+  * cell ids, flags, reward, step counters: single-buffered state that step k+1 rewrites in place, so
+    every gather first SNAPSHOTS them, stream-ordered behind step k, into one of two send slots
+    (T + 1 bytes per board: 3 MiB at 1M 4x4 boards) and the collective reads the slot.
 The RECEIVE side (obs_all and the padded / byte / cell-id images it is assembled from) is single-buffered, and all three
 forms assemble into the same observation image: ONE gather in flight per gatherer.  Wait for gather k before issuing gather
 k+1 - issuing a second one while a handle is unfinished raises RuntimeError instead of letting collective k+1 overwrite what
@@ -33,20 +48,23 @@ handle k is about to finish from.  (The send side's two slots exist because gath
 backend's stream when step k+1 - and the snapshot / padded copy of gather k+1 - are enqueued on the caller's.)
 
 Shards may differ in size (shard_bounds hands out sizes that differ by at most one board):
-all-gather needs equal pieces, so every rank then sends max-shard-size boards (padded) and the
+the collectives need equal pieces, so every rank then sends max-shard-size boards (padded) and the
 pieces are compacted after the collective.  The kernels only ever see base pointers of whole
 buffers (16-B aligned by the allocator), never a shard's offset inside one: with odd board sizes
 12*S*S*offset is not a multiple of 16 and ts_encode / ts_expand_u8 refuse such pointers.
 
 torch.distributed's "nccl" backend is RCCL on ROCm; the same code runs on "gloo" for the CPU
-tests, which inject an encoder because the HIP library needs a GPU.  `all_gather_fn` replaces
-the collective itself (tests run several ranks as threads of one process on one GPU with it).
+tests, which inject an encoder because the HIP library needs a GPU.  `all_gather_fn` / `gather_fn` replace
+the collective itself (tests run several ranks as threads of one process on one GPU with them).
 """
 import ctypes as C
 from types import SimpleNamespace
 
 import torch
 import torch.distributed as dist
+
+# TS_FLAG_* of include/tiler_slider.h (this module must stay importable without the HIP library: the CPU tests run it on gloo)
+_FLAG_IS_WON, _FLAG_INVALID_MOVE, _FLAG_SUCCESS, _FLAG_TIMEOUT, _FLAG_STEPPED_DONE = 0x01, 0x02, 0x04, 0x08, 0x10
 
 
 def shard_bounds(total, world_size, rank):
@@ -61,6 +79,12 @@ def make_sharded_env(total_boards, rank, world_size, seed=0, **kw):
     from .vec_env import VecTilerSliderEnv
     lo, hi = shard_bounds(total_boards, world_size, rank)
     return VecTilerSliderEnv.random(hi - lo, seed=seed, board_offset=lo, **kw)
+
+
+def done_from_flags(flags):
+    """The `done` latch after the step that wrote `flags` (environment.py:137-141: done = won or timeout; a board stepped while
+    done keeps it - TS_FLAG_STEPPED_DONE; a board that was reset in place or refused a bad action is live)."""
+    return (flags & (_FLAG_IS_WON | _FLAG_TIMEOUT | _FLAG_STEPPED_DONE)) != 0
 
 
 def _hip_expand(env, src_u8, dst_f32):
@@ -79,11 +103,11 @@ def _hip_encode(env, shard):
 
 
 class GatherHandle:
-    """An all-gather in flight; wait() completes it (stream-ordered on CUDA/ROCm) and returns
-    the assembled observations."""
+    """A hand-off in flight; wait() completes it (stream-ordered on CUDA/ROCm) and returns the assembled observations
+    (None on the ranks that are not the root of a gather-to-root); `info` then holds the gathered flags / done / reward."""
 
     def __init__(self, work, finish):
-        self._work, self._finish, self._result = work, finish, None
+        self._work, self._finish, self._result, self.info = work, finish, None, None
 
     @property
     def finished(self):
@@ -94,68 +118,98 @@ class GatherHandle:
             for w in self._work:
                 if w is not None:
                     w.wait()
-            self._result = self._finish()
+            self._result, self.info = self._finish()
             self._finish = None
         return self._result
 
 
 class ObservationGatherer:
-    """Reassembles every rank's boards on every rank (all-gather): rank r's boards are rows
+    """Reassembles every rank's boards on every rank (all-gather) or on `root` (gather): rank r's boards are rows
     [offsets[r], offsets[r] + counts[r]) of the result."""
 
-    def __init__(self, env, world_size, group=None, encode_fn=None, expand_fn=None, all_gather_fn=None):
+    def __init__(self, env, world_size, group=None, encode_fn=None, expand_fn=None, all_gather_fn=None, root=None,
+                 gather_fn=None, rank=None, with_step_count=False):
         self.env, self.world, self.group = env, int(world_size), group
         self.encode_fn = encode_fn or _hip_encode
         self.expand_fn = expand_fn or _hip_expand
         self._all_gather = all_gather_fn or self._dist_all_gather
+        self._gather_to_root = gather_fn or self._dist_gather
+        self.root = None if root is None else int(root)
+        if rank is None:
+            rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+        self.rank = int(rank)
+        if self.root is not None and not 0 <= self.root < self.world:
+            raise ValueError(f"root must be a rank of the group (0..{self.world - 1})")
+        self.receives = self.root is None or self.root == self.rank  # does this rank end up with the gathered boards?
         n, S = env.num_envs, env.size
-        dev = env._obs.device
+        obs0 = getattr(env, "_obs", None)
+        dev = env._pos.device
         self.device = dev
-        # shard sizes: one small collective, once
+        self._obs_dtype = None if obs0 is None else obs0.dtype
+        # shard sizes: one small collective, once (every rank needs them: the padded piece size is max(counts))
         cnt = torch.tensor([n], dtype=torch.int64, device=dev)
         allc = torch.empty(self.world, dtype=torch.int64, device=dev)
-        self._gather_now(allc, cnt)
+        self._all_gather(allc.view(-1).view(torch.uint8), cnt.view(-1).view(torch.uint8), False)
         self.counts = [int(c) for c in allc.tolist()]
         self.nmax, self.total = max(self.counts), sum(self.counts)
         self.equal = min(self.counts) == self.nmax
         self.offsets = [sum(self.counts[:r]) for r in range(self.world)]
         nm, W = self.nmax, self.world
         obs_shape = (S, S, 3)
-        self.obs_all = torch.empty((self.total,) + obs_shape, dtype=torch.float32, device=dev)
+        recv = self.receives
+        self.obs_all = torch.empty((self.total,) + obs_shape, dtype=torch.float32, device=dev) if recv else None
         # With unequal shards the exchange is padded to nmax boards per rank: the padded float32 image
         # [world, nmax, ...] is where observations are received / encoded / expanded (base pointer only),
         # and compacted into obs_all from.  With equal shards it IS obs_all.
-        self._padded_obs = self.obs_all.view((W, nm) + obs_shape) if self.equal else \
-            torch.empty((W, nm) + obs_shape, dtype=torch.float32, device=dev)
+        self._padded_obs = None
+        if recv:
+            self._padded_obs = self.obs_all.view((W, nm) + obs_shape) if self.equal else \
+                torch.empty((W, nm) + obs_shape, dtype=torch.float32, device=dev)
         self._recv_u8 = (torch.empty((W, nm) + obs_shape, dtype=torch.uint8, device=dev)
-                         if env._obs.dtype == torch.uint8 else None)
+                         if recv and self._obs_dtype == torch.uint8 else None)
         self._send_pad = {}  # padded copies of this rank's buffers (only on ranks with n < nmax)
         self._pending = None  # the one gather that may be in flight (the receive side is single-buffered)
-        # compact state: dtypes come from the environment (uint8 cell ids up to 16x16, int16 above)
+        self.info = None      # what the last finished hand-off delivered besides the observations
+        # ---- the per-step message besides the observations: [cell ids |] flags [| reward] [| step counters], every segment
+        # padded to a multiple of 4 bytes (int32 views).  Two send slots (see the module docstring), one receive image.
         T = env._pos.shape[0]
-        self._pos_send = [torch.zeros((T, nm), dtype=env._pos.dtype, device=dev) for _ in range(2)]  # snapshots
-        self._pos_slot = self._pad_slot = 0
-        self.pos_all = torch.empty((W, T, nm), dtype=env._pos.dtype, device=dev)   # as received: rank-major
-        self.pos_flat = torch.empty((T, W * nm), dtype=env._pos.dtype, device=dev)  # SoA over all W * nmax boards
+        self._cell_bytes = env._pos.element_size()
+        self._has_reward = getattr(env, "_reward", None) is not None
+        self._has_steps = bool(with_step_count)
+        a4 = lambda x: (x + 3) & ~3
+        self._seg_pos = a4(T * nm * self._cell_bytes)
+        self._seg_flags = a4(nm)
+        self._off_reward = self._seg_flags
+        self._off_steps = self._off_reward + (4 * nm if self._has_reward else 0)
+        self._info_bytes = self._off_steps + (4 * nm if self._has_steps else 0)
+        self._msg_send = [torch.zeros(self._seg_pos + self._info_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._msg_slot = self._pad_slot = 0
+        self._msg_recv = torch.empty((W, self._seg_pos + self._info_bytes), dtype=torch.uint8, device=dev) if recv else None
+        self._info_recv = torch.empty((W, self._info_bytes), dtype=torch.uint8, device=dev) if recv else None  # observation forms
+        self.pos_flat = torch.empty((T, W * nm), dtype=env._pos.dtype, device=dev) if recv else None  # SoA over all W * nmax boards
+        self.flags_all = torch.empty(self.total, dtype=torch.uint8, device=dev) if recv else None
+        self.reward_all = torch.empty(self.total, dtype=torch.int32, device=dev) if recv and self._has_reward else None
+        self.step_count_all = torch.empty(self.total, dtype=torch.int32, device=dev) if recv and self._has_steps else None
         # static level tables: gathered once, kept in the SoA form of ONE batch of W * nmax boards
-        self.blk_flat = self._gather_cols_once(env._blk, "blk")
-        self.tgt_flat = self._gather_cols_once(env._tgt, "tgt") if env._tgt.numel() else \
-            torch.empty((env._tgt.shape[0], W * nm), dtype=env._tgt.dtype, device=dev)
+        self.blk_flat = self._gather_cols_once(env._blk)
+        self.tgt_flat = self._gather_cols_once(env._tgt) if env._tgt.numel() else \
+            (torch.empty((env._tgt.shape[0], W * nm), dtype=env._tgt.dtype, device=dev) if recv else None)
         lines = getattr(env, "_lines", None)
         self.lines_flat = None
         if lines is not None:
-            la = torch.empty((W, nm, lines.shape[1]), dtype=lines.dtype, device=dev)
-            self._gather_now(la, self._padded_rows(lines, "lines"))
-            self.lines_flat = la.view(W * nm, lines.shape[1])  # board-major records: rank-major is already flat
+            la = torch.empty((W, nm, lines.shape[1]), dtype=lines.dtype, device=dev) if recv else None
+            self._gather(la, self._padded_rows(lines, "lines"), False)
+            self.lines_flat = la.view(W * nm, lines.shape[1]) if recv else None  # board-major records: rank-major is already flat
         self._send_pad.pop("lines", None)
-        self.bytes_per_step = {"obs_f32": nm * S * S * 12,
-                               "compact_state_then_encode": T * nm * env._pos.element_size(),
-                               "obs_u8_then_expand": nm * S * S * 3}
+        info_b = nm * (1 + (4 if self._has_reward else 0) + (4 if self._has_steps else 0))
+        self.bytes_per_step = {"obs_f32": nm * S * S * 12 + info_b,
+                               "compact_state_then_encode": T * nm * self._cell_bytes + info_b,
+                               "obs_u8_then_expand": nm * S * S * 3 + info_b}
 
     # ------------------------------------------------------------------ padding helpers
     def _padded_rows(self, t, key):
         """[n, ...] -> [nmax, ...]: the tensor itself when this rank holds nmax boards.  Observations go
-        through two alternating pad buffers, like the snapshots of `pos` (gather k may still be reading one
+        through two alternating pad buffers, like the snapshots of the state (gather k may still be reading one
         when gather k+1 is issued)."""
         if t.shape[0] == self.nmax:
             return t
@@ -168,37 +222,95 @@ class ObservationGatherer:
         buf[:t.shape[0]].copy_(t)
         return buf
 
-    def _gather_cols_once(self, t, key):
+    def _gather_cols_once(self, t):
         """SoA [rows, n] of every rank -> [rows, world * nmax] (rank r's boards at columns r * nmax ...)."""
         rows = t.shape[0]
         send = t
         if t.shape[1] != self.nmax:
             send = torch.zeros((rows, self.nmax), dtype=t.dtype, device=t.device)
             send[:, :t.shape[1]].copy_(t)
-        recv = torch.empty((self.world, rows, self.nmax), dtype=t.dtype, device=t.device)
-        self._gather_now(recv, send)
-        return recv.permute(1, 0, 2).reshape(rows, self.world * self.nmax).contiguous()
+        recv = torch.empty((self.world, rows, self.nmax), dtype=t.dtype, device=t.device) if self.receives else None
+        self._gather(recv, send, False)
+        return recv.permute(1, 0, 2).reshape(rows, self.world * self.nmax).contiguous() if self.receives else None
 
     def _dist_all_gather(self, out_u8, shard_u8, async_op):
         return dist.all_gather_into_tensor(out_u8, shard_u8, group=self.group, async_op=async_op)
 
-    def _gather(self, out, shard, async_op):
-        # flat byte views: every backend accepts uint8 [world * nbytes] <- [nbytes]; an all-gather moves
-        # bytes, and neither RCCL nor gloo knows int16 (the cell ids above 16x16)
-        return self._all_gather(out.view(-1).view(torch.uint8), shard.contiguous().view(-1).view(torch.uint8), async_op)
+    def _dist_gather(self, out_u8, shard_u8, async_op):
+        """Gather to `root`: out_u8 is the flat receive image [world * nbytes] on the root, None elsewhere."""
+        pieces = list(out_u8.view(self.world, -1).unbind(0)) if out_u8 is not None else None
+        dst = self.root if self.group is None else dist.get_global_rank(self.group, self.root)
+        return dist.gather(shard_u8, pieces, dst=dst, group=self.group, async_op=async_op)
 
-    def _gather_now(self, out, shard):
-        self._gather(out, shard, False)
+    def _gather(self, out, shard, async_op):
+        # flat byte views: every backend accepts uint8 [world * nbytes] <- [nbytes]; a gather moves
+        # bytes, and neither RCCL nor gloo knows int16 (the cell ids above 16x16)
+        shard_u8 = shard.contiguous().view(-1).view(torch.uint8)
+        if self.root is None:
+            return self._all_gather(out.view(-1).view(torch.uint8), shard_u8, async_op)
+        return self._gather_to_root(out.view(-1).view(torch.uint8) if out is not None else None, shard_u8, async_op)
 
     def _compact(self):
         """padded [world, nmax, ...] -> obs_all rows, dropping each shard's padding (torch copies: any alignment)."""
+        if not self.receives:
+            return None
         if not self.equal:
             for r in range(self.world):
                 self.obs_all[self.offsets[r]:self.offsets[r] + self.counts[r]].copy_(self._padded_obs[r, :self.counts[r]])
         return self.obs_all
 
+    # ------------------------------------------------------------------ flags / reward / step counters
+    def _snapshot_message(self, with_pos):
+        """This rank's message of the step just taken, copied (stream-ordered behind that step) into the next send slot; returns
+        the bytes to send: the whole slot (cell ids + info, compact form) or its info part (observation forms)."""
+        env, n, nm = self.env, self.env.num_envs, self.nmax
+        msg = self._msg_send[self._msg_slot]
+        self._msg_slot ^= 1
+        T = env._pos.shape[0]
+        if with_pos and T:
+            msg[:T * nm * self._cell_bytes].view(env._pos.dtype).view(T, nm)[:, :n].copy_(env._pos)
+        info = msg[self._seg_pos:]
+        info[:n].copy_(env._flags)
+        if self._has_reward:
+            info[self._off_reward:self._off_reward + 4 * nm].view(torch.int32)[:n].copy_(env._reward)
+        if self._has_steps:
+            info[self._off_steps:self._off_steps + 4 * nm].view(torch.int32)[:n].copy_(env._step_count)
+        return msg if with_pos else info
+
+    def _unpack_info(self, recv_info):
+        """recv_info: uint8 [world, info_bytes] as received -> flags_all / reward_all / step_count_all (padding dropped) and the
+        info dict of the gathered batch."""
+        nm, W = self.nmax, self.world
+        words = lambda off: recv_info[:, off:off + 4 * nm].view(torch.int32)  # [world, nmax] int32 (rows 4-B aligned by construction)
+        if self.equal:  # one strided copy per array
+            self.flags_all.view(W, nm).copy_(recv_info[:, :nm])
+            if self._has_reward:
+                self.reward_all.view(W, nm).copy_(words(self._off_reward))
+            if self._has_steps:
+                self.step_count_all.view(W, nm).copy_(words(self._off_steps))
+        else:
+            for r in range(W):
+                lo, c = self.offsets[r], self.counts[r]
+                self.flags_all[lo:lo + c].copy_(recv_info[r, :c])
+                if self._has_reward:
+                    self.reward_all[lo:lo + c].copy_(words(self._off_reward)[r, :c])
+                if self._has_steps:
+                    self.step_count_all[lo:lo + c].copy_(words(self._off_steps)[r, :c])
+        f = self.flags_all
+        info = {"flags": f, "done": done_from_flags(f), "is_won": (f & _FLAG_IS_WON) != 0, "invalid_move": (f & _FLAG_INVALID_MOVE) != 0,
+                "success": (f & _FLAG_SUCCESS) != 0, "timeout": (f & _FLAG_TIMEOUT) != 0}
+        if self._has_reward:
+            info["reward"] = self.reward_all
+        if self._has_steps:
+            info["step_count"] = self.step_count_all  # AFTER the step's increment (the environment's counter; StepInfo subtracts it back)
+        return info
+
     def _finish(self, work, fn, async_op):
-        h = GatherHandle(work, fn)
+        def fin():
+            res = fn()
+            self.info = res[1]
+            return res
+        h = GatherHandle(work, fin)
         self._pending = h
         return h if async_op else h.wait()
 
@@ -214,52 +326,65 @@ class ObservationGatherer:
             raise ValueError("an async gather of observations overlaps the next step(), which would overwrite the "
                              "buffer being sent: build the environment with obs_buffers=2")
 
+    def _info_collective(self, async_op):
+        """The second, small collective of the observation forms: flags (+ reward, step counters) of the step just taken."""
+        return self._gather(self._info_recv, self._snapshot_message(False), async_op), self._info_recv
+
     # ------------------------------------------------------------------ the three hand-offs
     def gather_observations(self, obs=None, async_op=False):
-        """all-gather of float32 observations; `obs` defaults to the environment's current
+        """gather of float32 observations (+ flags / reward); `obs` defaults to the environment's current
         observation buffer (pass the tensor step() returned when the environment double-buffers)."""
         obs = self.env._obs if obs is None else obs
-        if obs.dtype != torch.float32:
-            raise ValueError("gather_observations needs a float32 environment; use gather_u8_and_expand")
+        if obs is None or obs.dtype != torch.float32:
+            raise ValueError("gather_observations needs a float32 environment; use gather_u8_and_expand or gather_compact_and_encode")
         self._check_async_obs(async_op)
         self._require_idle()
         w = self._gather(self._padded_obs, self._padded_rows(obs, "obs"), async_op)
-        return self._finish([w], self._compact, async_op)
+        wi, recv_info = self._info_collective(async_op)
+
+        def fin():
+            if not self.receives:
+                return None, None
+            return self._compact(), self._unpack_info(recv_info)
+        return self._finish([w, wi], fin, async_op)
 
     def gather_u8_and_expand(self, obs=None, async_op=False):
-        if self._recv_u8 is None:
+        if self._obs_dtype != torch.uint8:
             raise ValueError('gather_u8_and_expand needs an environment built with obs_dtype="uint8"')
         obs = self.env._obs if obs is None else obs
         self._check_async_obs(async_op)
         self._require_idle()
         w = self._gather(self._recv_u8, self._padded_rows(obs, "obs_u8"), async_op)
+        wi, recv_info = self._info_collective(async_op)
 
         def fin():  # ONE launch over everything received (padding boards included), then drop the padding
+            if not self.receives:
+                return None, None
             self.expand_fn(self.env, self._recv_u8, self._padded_obs)
-            return self._compact()
-        return self._finish([w], fin, async_op)
+            return self._compact(), self._unpack_info(recv_info)
+        return self._finish([w, wi], fin, async_op)
 
     def gather_compact_and_encode(self, async_op=False):
+        """ONE collective: cell ids + flags (+ reward, step counters) of the step just taken; the receiving rank(s) re-encode all
+        boards with one ts_encode.  The environment needs no observation of its own (obs_dtype=None)."""
         env = self.env
         self._require_idle()
-        w = None
-        if env._pos.numel():
-            # snapshot, stream-ordered behind the step that produced these cells: the collective (on the
-            # backend's stream) reads the slot, never `pos` itself, which the next step rewrites in place
-            send = self._pos_send[self._pos_slot]
-            self._pos_slot ^= 1
-            send[:, :env._pos.shape[1]].copy_(env._pos)
-            w = self._gather(self.pos_all, send, async_op)
+        # snapshot, stream-ordered behind the step that produced it: the collective (on the backend's stream) reads the
+        # slot, never `pos` / `flags` themselves, which the next step rewrites in place
+        w = self._gather(self._msg_recv, self._snapshot_message(True), async_op)
 
         def fin():
+            if not self.receives:
+                return None, None
             # rank-major [world, T, nmax] -> the SoA rows of one batch of world * nmax boards, then ONE
             # ts_encode launch over all of them.  The padding boards of a short shard hold zeros, which
             # the kernels accept like any other cell ids; their rows are dropped by _compact.
             T = env._pos.shape[0]
             if T:
-                self.pos_flat.view(T, self.world, self.nmax).copy_(self.pos_all.permute(1, 0, 2))
+                cells = self._msg_recv[:, :T * self.nmax * self._cell_bytes].view(env._pos.dtype).view(self.world, T, self.nmax)
+                self.pos_flat.view(T, self.world, self.nmax).copy_(cells.permute(1, 0, 2))
             self.encode_fn(env, SimpleNamespace(n_boards=self.world * self.nmax, pos=self.pos_flat, tgt=self.tgt_flat,
                                                 blk=self.blk_flat, out=self._padded_obs.view((-1,) + tuple(self.obs_all.shape[1:])),
                                                 lines=self.lines_flat))
-            return self._compact()
+            return self._compact(), self._unpack_info(self._msg_recv[:, self._seg_pos:])
         return self._finish([w], fin, async_op)

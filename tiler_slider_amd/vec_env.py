@@ -85,7 +85,11 @@ class VecTilerSliderEnv:
                       (flag `autoreset`); their returned observation is the reset observation.
         obs_dtype   : "float32" = the reference's observation format (default); "uint8" = the
                       same values as bytes, a quarter of the memory traffic (every value of the
-                      reference observation is an integer 0..255, so nothing is lost).
+                      reference observation is an integer 0..255, so nothing is lost); None = the
+                      environment keeps NO observation (ts_step_out.obs = NULL): reset() and step()
+                      return None in its place, encode() still renders one on request.  For actors whose
+                      consumer re-encodes from the cell ids (distributed.gather_compact_and_encode): the
+                      step then moves the state bytes only - 1M 4x4 boards 6.8 us instead of 30.
         obs_buffers : number of observation buffers step() cycles through (default 1: every step
                       overwrites the same tensor).  With 2, the tensor returned by step k stays
                       intact while step k+1 runs, so a consumer on another stream — the RCCL
@@ -108,8 +112,10 @@ class VecTilerSliderEnv:
                       k > 1: the constructor allocates up to k candidate observation buffers (all alive, so that each lands
                       elsewhere), rates each with eleven launches of the real step kernel at the library's static policy,
                       keeps the fastest and frees the rest; it stops as soon as both classes have been seen (about 2 ms and
-                      one observation buffer of transient memory per candidate, at most a quarter of the free memory; the
-                      launch policy is not touched, results never differ).  None (default): 16 for such two-stream
+                      one observation buffer of transient memory per candidate, at most a quarter of the free memory and 4 GiB in
+                      all - cfg2: 13 candidates; the launch policy is not touched, results never differ; every candidate freed
+                      is a device-synchronising hipFree).  The step time is therefore a property of the BOX: cfg2 runs at
+                      0.98 of the roofline where a fast region turns up and at 0.91 where none does.  None (default): 16 for such two-stream
                       environments (the fast class turned up within six candidates in 40 of 40 constructions between other
                       allocations of 0-6 GiB on one box, in none of 16 on another: r04_obs_candidates_robustness.log), 0
                       otherwise.  `observation_placement_report` holds the timings.
@@ -260,21 +266,31 @@ class VecTilerSliderEnv:
         self._done = self._zeros(N, torch.uint8)
         self._flags = self._zeros(N, torch.uint8)
         self._actions = self._zeros(N, torch.uint8)
-        obs_dtype = {"float32": torch.float32, "uint8": torch.uint8}.get(obs_dtype, obs_dtype)
-        if obs_dtype not in (torch.float32, torch.uint8):
-            raise ValueError("obs_dtype must be 'float32' or 'uint8'")
+        obs_dtype = {"float32": torch.float32, "uint8": torch.uint8, "none": None}.get(obs_dtype, obs_dtype)
+        if obs_dtype not in (torch.float32, torch.uint8, None):
+            raise ValueError("obs_dtype must be 'float32', 'uint8' or None")
         self.obs_dtype = obs_dtype
         if int(obs_buffers) < 1:
             raise ValueError("obs_buffers must be >= 1")
+        if obs_dtype is None and int(obs_buffers) != 1:
+            raise ValueError("obs_buffers needs an observation (obs_dtype=None keeps none)")
         if output_memory not in ("torch", "contiguous"):
             raise ValueError("output_memory must be 'torch' or 'contiguous'")
         self.output_memory = output_memory
         # what one step writes into the large outputs: beyond the Infinity Cache the kernels take their out-of-cache forms,
         # and the buffers come from physically contiguous memory (output_memory)
         self.onehot_channels = L.ts_onehot_channels(C.byref(self._dims))
-        per_board = self.size * self.size * ((4 if obs_dtype == torch.float32 else 1) * 3 + (4 * self.onehot_channels if with_onehot else 0))
-        self._outputs_beyond_cache = per_board * N > self._PLACEMENT_MIN_BYTES
-        self._obs_ring = [self._big_zeros((N, self.size, self.size, 3), obs_dtype) for _ in range(int(obs_buffers))]
+        obs_bytes = {torch.float32: 12, torch.uint8: 3, None: 0}[obs_dtype] * self.size * self.size
+        per_board = obs_bytes + (4 * self.onehot_channels * self.size * self.size if with_onehot else 0)
+        # Successive steps cycle through the observation ring, so what has to stay resident between two writes of one buffer is
+        # the WHOLE ring (+ the planes): a ring of two 201-MB buffers is a 402-MB working set, and the cache-resident launch
+        # forms (agent-scope stores) are the wrong ones for it - 39.4 us per step against 32.3 with the out-of-cache forms at
+        # 1M 4x4 boards, 30.2 with a single buffer (profiles/r05_ring_probe.log).  ts_dims.ring_bytes tells the library.
+        ring_bytes = (obs_bytes * int(obs_buffers) + (per_board - obs_bytes)) * N
+        self._dims.ring_bytes = ring_bytes if int(obs_buffers) > 1 else 0
+        self._outputs_beyond_cache = max(per_board * N, self._dims.ring_bytes) > self._PLACEMENT_MIN_BYTES
+        self._obs_ring = [self._big_zeros((N, self.size, self.size, 3), obs_dtype) if obs_dtype is not None else None
+                          for _ in range(int(obs_buffers))]
         self._obs_slot = 0
         self._obs = self._obs_ring[0]  # always the buffer the latest reset() / step() wrote
         self._reward = self._zeros(N, torch.int32) if with_reward else None
@@ -296,7 +312,7 @@ class VecTilerSliderEnv:
         self._bind_outputs()
         self.placement_report = self.observation_placement_report = None
         if obs_candidates is None:  # two large output streams: the observation buffer's place decides between two speeds
-            obs_candidates = 16 if (self._onehot is not None and self._outputs_beyond_cache and not self.host_mapped) else 0
+            obs_candidates = 16 if (self._onehot is not None and self.obs_dtype is not None and self._outputs_beyond_cache and not self.host_mapped) else 0
         if int(obs_candidates) > 1:
             self._choose_observation_buffers(int(obs_candidates))
         if int(placement_trials) >= 1:
@@ -309,14 +325,14 @@ class VecTilerSliderEnv:
         f32 = self.obs_dtype == torch.float32
         self._outs = [_cabi.StepOut(_ptr(self._flags), _ptr(o) if f32 else None, _ptr(self._reward),
                                     _ptr(self._onehot), _ptr(self._valid), None if f32 else _ptr(o), _ptr(self._valid4))
-                      for o in self._obs_ring]
+                      for o in self._obs_ring]  # (obs_dtype None: both observation pointers NULL)
         self._obs_slot = 0
         self._obs = self._obs_ring[0]
         self._out = self._outs[0]
 
     def _choose_observation_buffers(self, k):
         """`obs_candidates=k`: per slot of the observation ring, the fastest of up to k candidate buffers (see the constructor)."""
-        if self.host_mapped or self.num_envs == 0 or not self._outputs_beyond_cache:
+        if self.host_mapped or self.num_envs == 0 or not self._outputs_beyond_cache or self.obs_dtype is None:
             self.observation_placement_report = {"skipped": "outputs fit the Infinity Cache" if not self.host_mapped else "host-mapped"}
             return
         N, L = self.num_envs, _cabi.lib()
@@ -325,7 +341,10 @@ class VecTilerSliderEnv:
         # (Keeping the candidates apart with unused allocations in between - 1.2 GiB, or 1 / 2 / 4 / 8 GiB in turn - finds the
         # fast class LESS often than candidates that follow each other directly: 16 and 19 of 20 constructions against 20 of
         # 20, profiles/r04_obs_candidates_robustness.log.)
-        k = max(1, min(k, int(free * 0.25 // max(self._obs_ring[0].numel() * self._obs_ring[0].element_size(), 1))))  # transient memory: a quarter of what is free
+        # transient memory: at most a quarter of what is free AND at most _CANDIDATE_MAX_BYTES (4 GiB) in all - on a 288-GB part
+        # "a quarter of free memory" alone would let sixteen candidates of a large batch take tens of GB
+        one = max(self._obs_ring[0].numel() * self._obs_ring[0].element_size(), 1)
+        k = max(1, min(k, int(free * 0.25 // one), int(self._CANDIDATE_MAX_BYTES // one)))
         saved = (self._pos.clone(), self._step_count.clone(), self._done.clone(), self._flags.clone())
         acts = self._empty(N, torch.uint8)
         self._call("ts_fill_actions", N, C.c_uint64(0xAC710005), 0, 0, _ptr(acts))
@@ -345,9 +364,14 @@ class VecTilerSliderEnv:
         original = list(self._obs_ring)
         try:
             with torch.cuda.device(self.device):
-                for _ in range(300):  # clocks up before the first rating (tens of ms of load; a cold first rating reads 3-4 % slow
-                    # and would pass for the slow class)
-                    _cabi.check(L.ts_step(C.byref(self._dims), C.byref(self._state), _ptr(acts), _cabi.MODE_AUTORESET, C.byref(self._outs[0]), stream), "ts_step")
+                # Clocks up before the first rating counts (a cold first rating reads 3-4 % slow and would pass for the slow
+                # class) - but only as long as the clock is still rising: the first buffer is rated again and again until two
+                # consecutive ratings no longer improve by 1 % (two ratings when the GPU is warm; at most ~35 ms of load).
+                prev, settled, warmup_ratings = rate(self._outs[0]), 0, 1
+                while settled < 2 and warmup_ratings < 30:
+                    cur = rate(self._outs[0])
+                    settled = settled + 1 if cur >= prev * 0.99 else 0
+                    prev, warmup_ratings = cur, warmup_ratings + 1
                 for slot in range(len(self._obs_ring)):
                     cands, times = [self._obs_ring[slot]], []
                     for c in range(k):
@@ -361,7 +385,8 @@ class VecTilerSliderEnv:
                             break
                     best = min(range(len(times)), key=times.__getitem__)
                     self._obs_ring[slot] = cands[best]
-                    report.append({"us_per_step": [round(t, 2) for t in times], "chosen": best})
+                    report.append({"us_per_step": [round(t, 2) for t in times], "chosen": best, "candidates_allowed": k,
+                                   "clock_warmup_ratings": warmup_ratings})
                     del cands
         except BaseException:
             self._obs_ring = original
@@ -385,15 +410,16 @@ class VecTilerSliderEnv:
     # ts_dims on the real step kernel (~100 launches, state restored), and with placement_trials = k > 1 the same for up
     # to k candidate sets of output buffers, keeping the best.
     _PLACEMENT_MIN_BYTES = 256 << 20
+    _CANDIDATE_MAX_BYTES = 4 << 30  # obs_candidates: transient memory of all candidate observation buffers together
 
     def _tune_placement(self, trials):
         N = self.num_envs
-        out_bytes = sum(o.numel() * o.element_size() for o in self._obs_ring[:1])
+        out_bytes = sum(o.numel() * o.element_size() for o in self._obs_ring[:1] if o is not None)
         out_bytes += self._onehot.numel() * 4 if self._onehot is not None else 0
         if self.host_mapped or N == 0 or out_bytes <= self._PLACEMENT_MIN_BYTES:
             self.placement_report = {"skipped": "outputs fit the Infinity Cache" if not self.host_mapped else "host-mapped"}
             return
-        set_bytes = sum(o.numel() * o.element_size() for o in self._obs_ring) + (self._onehot.numel() * 4 if self._onehot is not None else 0)
+        set_bytes = sum(o.numel() * o.element_size() for o in self._obs_ring if o is not None) + (self._onehot.numel() * 4 if self._onehot is not None else 0)
         with torch.cuda.device(self.device):
             free, _ = torch.cuda.mem_get_info()
         trials = max(1, min(trials, 1 + int(free * 0.8 // max(set_bytes, 1))))
@@ -446,7 +472,7 @@ class VecTilerSliderEnv:
             with torch.cuda.device(self.device):
                 for k in range(trials):
                     if k:
-                        candidates.append(([self._big_zeros(tuple(o.shape), o.dtype) for o in self._obs_ring],
+                        candidates.append(([self._big_zeros(tuple(o.shape), o.dtype) if o is not None else None for o in self._obs_ring],
                                            self._big_zeros(tuple(self._onehot.shape), torch.float32) if self._onehot is not None else None))
                     self._obs_ring, self._onehot = candidates[k]
                     self._bind_outputs()
@@ -467,7 +493,8 @@ class VecTilerSliderEnv:
             self._obs_ring, self._onehot = chosen
             del candidates
             for o in self._obs_ring:
-                o.zero_()
+                if o is not None:
+                    o.zero_()
             if self._onehot is not None:
                 self._onehot.zero_()
             self._pos.copy_(saved[0]), self._step_count.copy_(saved[1]), self._done.copy_(saved[2]), self._flags.copy_(saved[3])
@@ -520,7 +547,8 @@ class VecTilerSliderEnv:
             self._call("ts_reset", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
         else:
             self._call("ts_reset", C.byref(self._dims), C.byref(self._state), None)
-            self._call("ts_encode_u8", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
+            if self.obs_dtype is not None:
+                self._call("ts_encode_u8", C.byref(self._dims), C.byref(self._state), _ptr(self._obs))
         self._sync_if_host()
         self._started = True
         return self._obs
@@ -635,7 +663,8 @@ class VecTilerSliderEnv:
 
     def encode(self, out=None):
         """The reference observation of the current boards (state.py:188-211)."""
-        out = self._empty(tuple(self._obs.shape), self._obs.dtype) if out is None else out
+        if out is None:
+            out = self._empty((self.num_envs, self.size, self.size, 3), self.obs_dtype or torch.float32)
         name = "ts_encode" if out.dtype == torch.float32 else "ts_encode_u8"
         self._call(name, C.byref(self._dims), C.byref(self._state), out.data_ptr())
         self._sync_if_host()
@@ -731,11 +760,16 @@ class _ContiguousBuffer:
             lib = C.CDLL("libamdhip64.so")
             lib.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
             lib.hipFree.argtypes = [C.c_void_p]
+            lib.hipGetLastError.restype = C.c_int
             cls._hip = lib
         p = C.c_void_p()
         with torch.cuda.device(device):
             rc = cls._hip.hipExtMallocWithFlags(C.byref(p), nbytes, 0x4)  # hipDeviceMallocContiguous
         if rc != 0 or not p.value:
+            # A failed HIP call leaves the thread's "last error" set until somebody reads it, and the library's launches check
+            # exactly that (ts_kernels.hip: finish_launch -> hipGetLastError) - unread, the error of this allocation would surface
+            # as TS_ERR_HIP on the next ts_prepare / ts_reset although the caller has fallen back to torch's allocator.
+            cls._hip.hipGetLastError()
             raise MemoryError(f"hipExtMallocWithFlags(contiguous, {nbytes} B) failed with {rc}")
         self.ptr, self.nbytes, self.device = p.value, nbytes, device
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (p.value, False), "version": 2, "strides": None}
