@@ -88,7 +88,7 @@ def test_overlapped_gathers_over_rccl_world1(rccl_world1, shape):
                 _check_handoff(torch, got, prev.info, expect[i - 1], (name, "gather", i - 1))
             prev = fn(True)
         _check_handoff(torch, prev.wait(), prev.info, expect[-1], (name, "last"))
-        assert bool(expect[-1][2].any()), "episodes of 5 steps: some boards must be done after 8"
+        assert any(bool(e[2].any()) for e in expect), "episodes of 5 steps: some step of 8 must leave boards done"
         torch.cuda.synchronize()
     with pytest.raises(ValueError):  # async gather of a single-buffered environment would race with the next step
         one = VecTilerSliderEnv.random(64, size=4, num_tiles=2, num_obstacles=2)
@@ -173,7 +173,7 @@ def test_gathers_with_threads_as_ranks(case):
         whole.step_async(_actions(torch, whole, i))
         expect.append((whole.encode().clone(), whole._flags.clone(), whole._done.clone().bool(), whole._reward.clone(), whole._step_count.clone()))
     torch.cuda.synchronize()
-    assert bool(expect[-1][2].any()) or total < 50
+    assert any(bool(e[2].any()) for e in expect) or total < 50  # episodes of 4 steps: the hand-off has terminal transitions to carry
     loop, loop_root = _Loopback(world), _Loopback(world)
     root = world - 1
     errors = []

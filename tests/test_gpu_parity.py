@@ -1206,7 +1206,7 @@ def test_observation_ring_takes_the_out_of_cache_forms_and_stays_exact(torch_cud
             L.ts_tuning(_cabi.TUNE_NT_THRESHOLD_BYTES, before)
 
 
-@pytest.mark.parametrize("S,T,K,mc,N", [(15, 32, 24, True, 1 << 18), (15, 32, 24, False, 100_003), (9, 4, 9, True, 300_001), (16, 255, 0, True, 5_000),
+@pytest.mark.parametrize("S,T,K,mc,N", [(15, 32, 24, True, 1 << 18), (15, 32, 24, False, 100_003), (9, 4, 9, True, 300_001), (16, 128, 0, True, 5_000),
                                         (20, 6, 30, True, 70_001), (32, 64, 100, False, 9_999), (32, 255, 200, True, 2_001), (17, 1, 3, False, 65)])
 def test_state_only_kernel_at_scale(torch_cuda, oracle, S, T, K, mc, N):
     """k_state (one board per lane, above 8x8) at co-residency scale, cfg4's full size among them: the stand-alone entry points and

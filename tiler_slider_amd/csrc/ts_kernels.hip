@@ -141,6 +141,9 @@
 #ifndef TS_MAX_BLOCK_LDS  // dynamic LDS a block may ask for (bytes)
 #define TS_MAX_BLOCK_LDS (64 * 1024)
 #endif
+#ifndef TS_EXP_MC_FLAG_WORD  // experiment (round 5, cfg4): the record word multi-colour launches of k_lines read the duplicate-target flag
+#define TS_EXP_MC_FLAG_WORD 16  // from.  16 = the shipped layout (second 64-byte half of the record); 0 = a word of the first half, so that
+#endif                          // a launch touches 64 of the record's 128 bytes (timing only: right answers only on levels without duplicates, S <= 15)
 #ifndef TS_SET_LDS_ATTR  // diagnostic: hipFuncSetAttribute(MaxDynamicSharedMemorySize) before k_small launches
 #define TS_SET_LDS_ATTR 0
 #endif
@@ -1413,7 +1416,7 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
       wx[i] = rec[mc ? 96 : 64 + line];
     } else {
       wC[i] = 0;
-      wx[i] = rec[mc ? 16 : 16 + line];
+      wx[i] = rec[mc ? TS_EXP_MC_FLAG_WORD : 16 + line];
     }
   }
   const cell_t *g_pos = reinterpret_cast<const cell_t *>(a.pos);
