@@ -658,6 +658,7 @@ def time_learner_side(cfg, n_all, device, L, stream):
 
 
 ASYMPTOTE_BOARDS = {"cfg1": 1 << 24, "cfg2": 1 << 22, "cfg4": (1 << 20) + (1 << 18)}  # >= 3 GB of large outputs per launch
+STATE_IN_CACHE_BOARDS = {"cfg1": 10 << 20, "cfg2": 5 << 19, "cfg4": 3 << 18}              # ~2.2 GB per launch: 8 x the Infinity Cache
 
 
 def time_env_steps(env, acts, steps, warm=10):
@@ -686,28 +687,40 @@ def action_buffers(n, count, device, L, stream, offset=0):
     return acts
 
 
-def time_asymptote(name, device, L, stream, output_memory="contiguous"):
+def time_asymptote(name, device, L, stream, output_memory="contiguous", boards=None):
     """The same shape and outputs at >= 3 GB of large outputs per launch: twelve times the 256 MiB Infinity Cache and more, where
     what the cache can absorb between two launches is a few per cent of the stream - the HBM-bound figure of this config's kernel
-    (every BASELINE config itself lies between 0.9 and 3.4 x the cache, where a third of the stream can be absorbed)."""
+    (every BASELINE config itself lies between 0.9 and 3.4 x the cache, where a third of the stream can be absorbed).
+    At that size the STATE a step re-reads (cells, targets, obstacles, counters, line tables: 14 .. 230 B per board) no longer fits
+    the cache either, and that - not the output stream - is what the rate falls on (profiles/r05_asymptote_probe.log: cfg1's shape
+    0.93 / 0.90 / 0.89 of 8 TB/s at 2.1 / 2.5 / 2.9 GB per launch, 0.67 at 3.4 GB, where its state passes 256 MiB; cfg4's 0.84 / 0.82
+    at 2.1 / 2.5 GB, 0.63 / 0.47 at 2.9 / 3.4 GB).  `with_state_in_cache` is the same measurement at ~2.2 GB per launch (8 x the cache),
+    the largest round size at which the state still fits."""
     import torch
     from tiler_slider_amd import VecTilerSliderEnv
     cfg = CONFIGS[name]
-    n = ASYMPTOTE_BOARDS[name]
-    bps = algorithmic_bytes_per_board_step(cfg["size"], cfg["tiles"], cfg["onehot"], cfg["reward"])
-    env = VecTilerSliderEnv.random(n, size=cfg["size"], num_tiles=cfg["tiles"], num_obstacles=cfg["obstacles"], seed=LEVEL_SEED,
+    n = boards or ASYMPTOTE_BOARDS[name]
+    S, T = cfg["size"], cfg["tiles"]
+    bps = algorithmic_bytes_per_board_step(S, T, cfg["onehot"], cfg["reward"])
+    env = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=cfg["obstacles"], seed=LEVEL_SEED,
                                    multi_color=True, max_steps=2**30, device=device, auto_reset=True, with_reward=cfg["reward"],
                                    with_onehot=cfg["onehot"], output_memory=output_memory, obs_candidates=0)
     env.reset()
     us = time_env_steps(env, action_buffers(n, 2, device, L, stream), 10, warm=3)
     desc = launch_description(env)
     gbs = bps * n / us / 1e3
+    large = 12 * S * S + (4 * S * S * (1 + 2 * T) + 4 if cfg["onehot"] else 0)  # observation (+ planes, reward): the streamed outputs
+    state = bps - large + (0 if S <= 8 else (64 if S <= 16 else 256))            # + the half of the ts_prepare record a multi-colour launch reads
     res = {"boards": n, "kernel": desc["name"], "kernel_us": us, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "frac_of_copy_ceiling": gbs / COPY_CEILING_GBS, "algorithmic_bytes_per_launch": bps * n,
            "times_infinity_cache": bps * n / INFINITY_CACHE_BYTES, "value": n / us * 1e6, "value_unit": "env-steps/s", "steps": 10,
+           "state_bytes_per_launch": state * n, "state_fits_infinity_cache": state * n < INFINITY_CACHE_BYTES,
+           "output_memory": [m["memory"] for m in env.output_memory_report],
            "launch": {k: desc[k] for k in ("boards_per_wave", "cached_every", "emit_edges", "xcd_piece", "blocks_per_cu", "blocks")}}
     del env
     torch.cuda.empty_cache()
+    if boards is None and name in STATE_IN_CACHE_BOARDS:
+        res["with_state_in_cache"] = time_asymptote(name, device, L, stream, output_memory, boards=STATE_IN_CACHE_BOARDS[name])
     return res
 
 
@@ -815,9 +828,14 @@ def time_gathers(env, ring, world, n, dist, torch, device, steps):
                 prev = None
                 for i in range(steps):
                     e.step_async(ring[i & 15])          # writes observation buffer i % 2
-                    if prev is not None:
+                    if prev is not None and not prev.two_phase:
                         prev.wait()                     # gather i-1 has read buffer (i-1) % 2 ...
-                    prev = fn(e, g, True)               # ... gather i starts behind step i, beside step i+1
+                    elif prev is not None:
+                        prev.receive()                  # compact form: message i-1 unpacked, the receive image is free ...
+                    cur = fn(e, g, True)                # ... gather i starts behind step i, beside step i+1
+                    if prev is not None and prev.two_phase:
+                        prev.wait()                     # ... and beside the learner's ts_encode of step i-1 (all boards)
+                    prev = cur
                 prev.wait()
 
             ts, to = timed(serial), timed(overlapped)

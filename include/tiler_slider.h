@@ -212,6 +212,34 @@ int32_t ts_encode_u8(const ts_dims *dims, const ts_state *st, uint8_t *obs_u8, v
  * aligned, dst 16-B aligned.  Build-defined helper; the values are exactly ts_encode's. */
 int32_t ts_expand_u8(const uint8_t *src, float *dst, int64_t count, void *stream);
 
+/* --- multi-GPU hand-off (ABI v6) --------------------------------------------------
+ * What a rank hands to the learner after a step besides (or instead of) its observations: ONE byte message per rank,
+ *    [ cell ids: cell_t [n_tiles][n_padded] ]   with TS_HANDOFF_CELLS (the compact form: the learner re-encodes with ts_encode)
+ *    [ flags:    uint8  [n_padded]          ]   always (done = flags & (IS_WON | TIMEOUT | STEPPED_DONE))
+ *    [ reward:   int32  [n_padded]          ]   with TS_HANDOFF_REWARD
+ *    [ steps:    int32  [n_padded]          ]   with TS_HANDOFF_STEP_COUNT (the counters after the step)
+ * every segment padded to a multiple of 16 bytes.  n_padded >= dims->n_boards is the largest shard of the group (a collective
+ * moves equal pieces); boards n_boards .. n_padded - 1 of a message are never written (zero them once).
+ * ref: what step() returns, environment.py:126-143 (obs, done, info) - the observation travels separately or is rebuilt.
+ *   ts_handoff_layout  host only: byte offsets of the four segments (-1 for an absent one) and the message size (return value,
+ *                      or a negative ts_status).
+ *   ts_pack_handoff    one launch: st->pos (+ flags, reward, st->step_count) -> msg, stream-ordered behind the step that wrote them,
+ *                      so the collective reads a snapshot while the next step rewrites the state in place.
+ *   ts_unpack_handoff  one launch on the receiving rank: `world` messages, `msg_stride` bytes apart -> the SoA cell rows of ONE
+ *                      batch of world * n_padded boards (pos_all: cell_t [n_tiles][world * n_padded], what ts_encode takes),
+ *                      and flags / reward / steps with every shard's padding dropped: rank r's boards land at
+ *                      offsets[r] .. offsets[r + 1] - 1 (offsets: DEVICE array of world + 1 int64, offsets[r + 1] - offsets[r] <=
+ *                      n_padded).  dims->n_boards is ignored here (the shards' sizes come from offsets). */
+#define TS_HANDOFF_CELLS 0x1u
+#define TS_HANDOFF_REWARD 0x2u
+#define TS_HANDOFF_STEP_COUNT 0x4u
+int64_t ts_handoff_layout(const ts_dims *dims, int64_t n_padded, uint32_t fields, int64_t offsets_out[4]);
+int32_t ts_pack_handoff(const ts_dims *dims, const ts_state *st, const uint8_t *flags, const int32_t *reward, int64_t n_padded,
+                        uint32_t fields, void *msg, void *stream);
+int32_t ts_unpack_handoff(const ts_dims *dims, int64_t n_padded, uint32_t fields, int32_t world, const int64_t *offsets,
+                          const void *msgs, int64_t msg_stride, void *pos_all, uint8_t *flags_all, int32_t *reward_all,
+                          int32_t *steps_all, void *stream);
+
 /* Build-defined extensions (absent from the reference, environment.py:5 says reward is
  * "handled separately"; no reference output exists to compare with — kernels and oracle are
  * pinned to NumPy expressions over the reference's recorded cells, tests/test_gpu_parity.py):

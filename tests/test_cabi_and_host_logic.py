@@ -88,6 +88,35 @@ def test_argument_validation_precedes_any_launch():
     assert L.ts_reset(C.byref(empty), C.byref(_cabi.State()), None, None) == _cabi.OK  # empty batch, no buffers
 
 
+def test_handoff_layout_matches_the_host_mirror_and_arguments_are_validated():
+    """The message of the multi-GPU hand-off (include/tiler_slider.h): ts_handoff_layout (what the kernels use) against
+    distributed.handoff_layout (what the gloo path uses); 16-byte segments; argument validation without a GPU."""
+    from tiler_slider_amd import _cabi
+    from tiler_slider_amd.distributed import HANDOFF_CELLS, HANDOFF_REWARD, HANDOFF_STEP_COUNT, handoff_layout
+    assert (HANDOFF_CELLS, HANDOFF_REWARD, HANDOFF_STEP_COUNT) == (_cabi.HANDOFF_CELLS, _cabi.HANDOFF_REWARD, _cabi.HANDOFF_STEP_COUNT)
+    L = _cabi.lib()
+    for S, T, n, nm in ((4, 2, 1 << 20, 1 << 20), (4, 2, 11, 12), (15, 32, 262143, 262144), (20, 6, 5, 5), (32, 255, 1, 3), (5, 0, 7, 7)):
+        d = _cabi.Dims(n, S, T, T, 1, 100, 0)
+        for fields in range(8):
+            out = (C.c_int64 * 4)()
+            total = L.ts_handoff_layout(C.byref(d), nm, fields, C.byref(out))
+            off, want = handoff_layout(T, 2 if S > 16 else 1, nm, fields)
+            assert (list(out), total) == (off, want), (S, T, n, nm, fields)
+            assert total % 16 == 0 and all(o % 16 == 0 for o in off if o >= 0)
+            assert (off[0] >= 0) == bool(fields & 1) and (off[2] >= 0) == bool(fields & 2) and (off[3] >= 0) == bool(fields & 4) and off[1] >= 0
+    d = _cabi.Dims(8, 4, 2, 2, 1, 100, 0)
+    assert L.ts_handoff_layout(C.byref(d), 7, 1, None) == _cabi.ERR_ARG       # padded size below the shard's
+    assert L.ts_handoff_layout(C.byref(d), 8, 8, None) == _cabi.ERR_ARG       # unknown field bit
+    assert L.ts_handoff_layout(C.byref(_cabi.Dims(8, 0, 2, 2, 1, 100, 0)), 8, 1, None) == _cabi.ERR_DIMS
+    st = _cabi.State(None, None, None, None, None, None, None)
+    assert L.ts_pack_handoff(C.byref(d), C.byref(st), None, None, 8, 1, None, None) == _cabi.ERR_NULL
+    assert L.ts_pack_handoff(C.byref(d), C.byref(st), None, None, 4, 1, None, None) == _cabi.ERR_ARG
+    assert L.ts_unpack_handoff(C.byref(d), 8, 1, 0, None, None, 64, None, None, None, None, None) == _cabi.ERR_ARG   # world < 1
+    assert L.ts_unpack_handoff(C.byref(d), 8, 1, 2, None, None, 16, None, None, None, None, None) == _cabi.ERR_ARG   # stride below a message
+    assert L.ts_unpack_handoff(C.byref(d), 8, 1, 2, None, None, 64, None, None, None, None, None) == _cabi.ERR_NULL
+    assert L.ts_pack_handoff(C.byref(_cabi.Dims(0, 4, 2, 2, 1, 100, 0)), None, None, None, 0, 1, None, None) == _cabi.OK  # empty shard
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from tiler_slider_amd import _cabi
     monkeypatch.setattr(_cabi, "_lib", None)

@@ -177,6 +177,31 @@ def _worker(rank, world, port, case, q):
         actor.step(orc, 100 + i)
         strict.step(orc, 100 + i)
         whole_strict.step(orc, 100 + i)
+        # two compact hand-offs pipelined, as a learner does: the second is issued once the first is RECEIVED (unpacked), before
+        # its ts_encode - which then runs beside the second collective and still encodes the first step's boards
+        h1 = g.gather_compact_and_encode(async_op=True)
+        obs1, flags1 = whole._obs.clone(), whole._flags.clone()
+        try:
+            g.gather_compact_and_encode(async_op=True)  # h1 not even received
+            ok = False
+        except RuntimeError as e:
+            ok &= "still in flight" in str(e)
+        ok &= torch.equal(h1.receive()["flags"], flags1) and h1.received and not h1.finished
+        try:
+            g.gather_observations(async_op=False)  # another form would receive into the image h1's encode writes
+            ok = False
+        except RuntimeError as e:
+            ok &= "still in flight" in str(e)
+        for e_ in (env, whole, env8, actor, strict, whole_strict):
+            e_.step(orc, 200 + i)
+        h2 = g.gather_compact_and_encode(async_op=True)
+        try:
+            h2.receive()  # would unpack over the cell rows h1 has yet to encode
+            ok = False
+        except RuntimeError as e:
+            ok &= "previous hand-off" in str(e)
+        ok &= torch.equal(h1.wait(), obs1) and h1.finished
+        ok &= torch.equal(h2.wait(), whole._obs) and info_matches(h2.info, whole)
     ok &= seen_done and seen_stepped_done  # the episodes were short enough for the interesting flags to occur
     q.put((rank, bool(ok)))
     dist.barrier()

@@ -83,10 +83,19 @@ def test_overlapped_gathers_over_rccl_world1(rccl_world1, shape):
             # float32 image of the boards after step i, and what else step() returned: flags, done, reward, step counters
             expect.append((env.encode(torch.empty_like(g32.obs_all)), env._flags.clone(), env._done.clone().bool(),
                            None if env._reward is None else env._reward.clone(), env._step_count.clone()))
-            if prev is not None:
+            if prev is not None and not prev.two_phase:
                 got = prev.wait()
                 _check_handoff(torch, got, prev.info, expect[i - 1], (name, "gather", i - 1))
-            prev = fn(True)
+                prev = fn(True)
+            elif prev is not None:  # compact form, pipelined as in bench.py: receive (unpack) step i-1's message, issue gather i,
+                prev.receive()      # THEN launch the ts_encode of step i-1's boards - beside collective i
+                info_before = {k: prev.info[k].clone() for k in prev.info}
+                cur = fn(True)
+                got = prev.wait()
+                _check_handoff(torch, got, info_before, expect[i - 1], (name, "pipelined gather", i - 1))
+                prev = cur
+            else:
+                prev = fn(True)
         _check_handoff(torch, prev.wait(), prev.info, expect[-1], (name, "last"))
         assert any(bool(e[2].any()) for e in expect), "episodes of 5 steps: some step of 8 must leave boards done"
         torch.cuda.synchronize()
@@ -225,3 +234,55 @@ def test_gathers_with_threads_as_ranks(case):
         t.join(timeout=600)
     assert not errors, errors
     assert not any(t.is_alive() for t in threads)
+
+
+@pytest.mark.parametrize("S,T,K,counts", [(4, 2, 2, (1_200_000, 1_200_000)), (4, 2, 2, (1600, 1600, 1584)), (5, 3, 2, (77, 76, 76)),
+                                          (15, 32, 24, (4099, 4098)), (20, 6, 30, (333, 333, 332, 332)), (3, 1, 0, (5, 4))])
+def test_pack_and_unpack_launches_match_the_torch_copies(S, T, K, counts):
+    """ts_pack_handoff / ts_unpack_handoff (one launch each) against the torch copies the gloo path uses, byte for byte: every
+    field combination, 16-byte-aligned rows (uint4 lanes, grid-stride beyond 1024 blocks per row at 1.2M boards) and odd shard
+    sizes (single bytes), uint16 cell ids."""
+    import types
+    import torch
+    from tiler_slider_amd import VecTilerSliderEnv
+    from tiler_slider_amd import distributed as D
+    dev = torch.device("cuda", 0)
+    world, nm, total = len(counts), max(counts), sum(counts)
+    envs = []
+    lo = 0
+    for r, n in enumerate(counts):
+        e = VecTilerSliderEnv.random(n, size=S, num_tiles=T, num_obstacles=K, seed=5, board_offset=lo, multi_color=True, max_steps=3,
+                                     auto_reset=True, with_reward=True, obs_dtype=None, device=dev)
+        e.reset()
+        for i in range(4):
+            e.step_async(_actions(torch, e, i, lo))
+        envs.append(e)
+        lo += n
+    torch.cuda.synchronize()
+    cpu = lambda t: t.cpu()
+    offsets = [sum(counts[:r]) for r in range(world)]
+    for fields in range(8):
+        nbytes = D.handoff_layout(T, envs[0]._pos.element_size(), nm, fields)[1]
+        got_msgs = torch.zeros((world, nbytes + 32), dtype=torch.uint8, device=dev)  # a stride beyond the message: the tail stays zero
+        want_msgs = torch.zeros((world, nbytes + 32), dtype=torch.uint8)
+        for r, e in enumerate(envs):
+            D._hip_pack(e, got_msgs[r], nm, fields)
+            twin = types.SimpleNamespace(num_envs=e.num_envs, _pos=cpu(e._pos), _flags=cpu(e._flags), _reward=cpu(e._reward), _step_count=cpu(e._step_count))
+            D._torch_pack(twin, want_msgs[r], nm, fields)
+        torch.cuda.synchronize()
+        assert torch.equal(got_msgs.cpu(), want_msgs), (fields, "pack")
+
+        def receiver(device, env):
+            g = types.SimpleNamespace(env=env, nmax=nm, world=world, offsets=offsets, counts=list(counts))
+            g.pos_flat = torch.full((T, world * nm), 0xEE, dtype=env._pos.dtype, device=device)
+            g.flags_all = torch.full((total,), 0xEE, dtype=torch.uint8, device=device)
+            g.reward_all = torch.full((total,), -7, dtype=torch.int32, device=device)
+            g.step_count_all = torch.full((total,), -7, dtype=torch.int32, device=device)
+            g._offsets_dev = torch.tensor(offsets + [total], dtype=torch.int64, device=device)
+            return g
+        gg, gw = receiver(dev, envs[0]), receiver("cpu", types.SimpleNamespace(_pos=cpu(envs[0]._pos)))
+        D._hip_unpack(gg, got_msgs, fields)
+        D._torch_unpack(gw, want_msgs, fields)
+        torch.cuda.synchronize()
+        for name in ("pos_flat", "flags_all", "reward_all", "step_count_all"):  # fields that are absent leave their array untouched on both sides
+            assert torch.equal(getattr(gg, name).cpu(), getattr(gw, name)), (fields, "unpack", name)

@@ -1223,7 +1223,8 @@ def test_state_only_kernel_at_scale(torch_cuda, oracle, S, T, K, mc, N):
     bare = VecTilerSliderEnv.from_arrays(S, blk, init, tgt, multi_color=mc, max_steps=7, auto_reset=True, obs_dtype=None,
                                          with_reward=True, with_valid_moves=True)
     kinds = {_cabi.describe_launch(bare._dims, op, outs)["name"] for op, outs in ((_cabi.OP_OBSERVE, _cabi.OUT_FLAGS), (_cabi.OP_OBSERVE, _cabi.OUT_VALID4))}
-    assert kinds == {"k_state<%s, false>" % ("true" if S > 16 else "false"), "k_state<%s, true>" % ("true" if S > 16 else "false")}
+    wide, batch = "true" if S > 16 else "false", 8 if T <= 8 else 16
+    assert kinds == {f"k_state<{wide}, false, {batch}>", f"k_state<{wide}, true, {batch}>"}
     ref.reset(), bare.reset()
 
     def entry_points(ctx):

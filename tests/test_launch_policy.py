@@ -99,7 +99,7 @@ CLIFFS = {
              (1200, -1): ("k_small<8, 4, false, true>", 1, 64, 0, 3, 32, 1, 8), (1200, 1): ("k_small<8, 4, false, true>", 1, 32, 0, 3, 0, 1, 8)},
     (15, 32): {(256, -1): ("k_lines<false, 16, 2, false, false>", 0, 4, 0, 0, -1, 4, 0), (256, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 3, 16, 1, 18),
                (704, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 3, 16, 1, 18), (1024, -1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 2, 16, 1, 18),
-               (1200, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 2, 16, 1, 18)},
+               (1200, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 0, 16, 1, 18)},  # (a single edge beyond 1 GiB: up to 112 MiB of it)
     (20, 6): {(256, -1): ("k_lines<true, 32, 1, false, false>", 0, 2, 0, 0, -1, 4, 0), (256, 1): ("k_lines<true, 32, 1, true, false>", 1, 2, 16, 3, 16, 1, 22),
               (512, -1): ("k_lines<true, 32, 1, true, false>", 1, 2, 16, 3, 16, 1, 22), (512, 1): ("k_lines<true, 32, 1, true, false>", 1, 2, 32, 3, 16, 1, 22),
               (704, -1): ("k_lines<true, 32, 1, true, false>", 1, 2, 32, 3, 16, 1, 22), (704, 1): ("k_lines<true, 32, 1, true, false>", 1, 2, 0, 3, 16, 1, 22),
@@ -124,11 +124,14 @@ def test_state_only_launches():
         r = describe(dims(1 << 18, 15, 32), op, outs)
         extras = int(bool(outs & (RW | VALID | VALID4)))
         assert (r["name"], r["boards_per_wave"], r["waves_per_block"], r["blocks"], r["lds_bytes_block"], r["out_of_cache"]) == \
-            (f"k_state<false, {'true' if extras else 'false'}>", 64, 4, 1024, 32768, 0), (op, outs, r)
+            (f"k_state<false, {'true' if extras else 'false'}, 16>", 64, 4, 1024, 32768, 0), (op, outs, r)
     wide = describe(dims(1 << 15, 32, 64), OBSERVE, FLAGS)
-    assert (wide["name"], wide["waves_per_block"], wide["blocks"], wide["lds_bytes_block"]) == ("k_state<true, false>", 2, 256, 65536)
+    assert (wide["name"], wide["waves_per_block"], wide["blocks"], wide["lds_bytes_block"]) == ("k_state<true, false, 16>", 2, 256, 65536)
     assert describe(dims(1 << 18, 15, 32, mc=0), OBSERVE, RW)["name"] == "k_lines<false, 16, 2, false, true>"
-    assert describe(dims(1 << 18, 15, 32, mc=0), OBSERVE, FLAGS)["name"] == "k_state<false, false>"
+    assert describe(dims(1 << 18, 15, 32, mc=0), OBSERVE, FLAGS)["name"] == "k_state<false, false, 16>"
+    # eight cells in flight per lane up to eight tiles, sixteen above (the slots beyond a board's tiles are loads like any other)
+    assert [describe(dims(1 << 18, 9, t), OBSERVE, VALID)["name"] for t in (1, 8, 9)] == ["k_state<false, true, 8>"] * 2 + ["k_state<false, true, 16>"]
+    assert describe(dims(1 << 16, 20, 6), STEP, 0)["name"] == "k_state<true, false, 8>"
     L = _cabi.lib()
     before = L.ts_tuning(_cabi.TUNE_STATE_ONLY, 0)
     try:

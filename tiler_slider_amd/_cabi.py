@@ -26,7 +26,8 @@ TUNE_DEAL, TUNE_MT_WINDOW, TUNE_SMALL_BPW, TUNE_CACHED_EVERY, TUNE_STATE_ONLY = 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",
            "ts_encode_u8", "ts_expand_u8", "ts_encode_onehot", "ts_reward", "ts_generate", "ts_fill_actions",
-           "ts_lines_words", "ts_prepare", "ts_generate_mt19937", "ts_tuning", "ts_valid_moves4", "ts_describe_launch")
+           "ts_lines_words", "ts_prepare", "ts_generate_mt19937", "ts_tuning", "ts_valid_moves4", "ts_describe_launch",
+           "ts_handoff_layout", "ts_pack_handoff", "ts_unpack_handoff")
 
 
 class Dims(C.Structure):
@@ -46,6 +47,7 @@ class StepOut(C.Structure):
 
 
 OP_STEP, OP_RESET, OP_OBSERVE = 0, 1, 2
+HANDOFF_CELLS, HANDOFF_REWARD, HANDOFF_STEP_COUNT = 0x1, 0x2, 0x4
 OUT_OBS, OUT_REWARD, OUT_ONEHOT, OUT_VALID, OUT_OBS_U8, OUT_VALID4, OUT_FLAGS = 0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40
 KERNEL_NAMES = {0: "none", 1: "k_small", 2: "k_multi", 3: "k_deal", 4: "k_lines", 5: "k_state"}
 
@@ -220,7 +222,11 @@ def lib():
     L.ts_check_dims.restype = C.c_int32
     L.ts_describe_launch.argtypes = [DP, C.c_uint32, C.c_uint32, C.POINTER(LaunchDesc)]
     L.ts_describe_launch.restype = C.c_int32
-    for name, args in (("ts_reset", [DP, SP, P, P]),
+    L.ts_handoff_layout.argtypes = [DP, C.c_int64, C.c_uint32, C.POINTER(C.c_int64 * 4)]
+    L.ts_handoff_layout.restype = C.c_int64
+    for name, args in (("ts_pack_handoff", [DP, SP, P, P, C.c_int64, C.c_uint32, P, P]),
+                       ("ts_unpack_handoff", [DP, C.c_int64, C.c_uint32, C.c_int32, P, P, C.c_int64, P, P, P, P, P]),
+                       ("ts_reset", [DP, SP, P, P]),
                        ("ts_step", [DP, SP, P, C.c_uint32, C.POINTER(StepOut), P]),
                        ("ts_valid_moves", [DP, SP, P, P]), ("ts_valid_moves4", [DP, SP, P, P]), ("ts_is_won", [DP, SP, P, P]), ("ts_prepare", [DP, SP, P, P]),
                        ("ts_encode", [DP, SP, P, P]), ("ts_encode_u8", [DP, SP, P, P]),

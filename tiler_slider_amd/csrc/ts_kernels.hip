@@ -1722,12 +1722,11 @@ __global__ __launch_bounds__(TS_LINES_WAVES * 64) void k_lines(const KArgs a, co
 // Tiles are walked in a runtime loop, eight loads in flight.
 // ref: explainrl/environment/state.py:120-186, environment.py:100-171 - the same rules as k_lines, in the same order.
 // ------------------------------------------------------------------------------------------
-template <bool WIDE, bool EXTRAS>
+template <bool WIDE, bool EXTRAS, int kBatch>
 __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const uint32_t invS) {
   using cell_t = typename std::conditional<WIDE, uint16_t, uint8_t>::type;
   constexpr int NLN = WIDE ? 32 : 16;
   constexpr int REC = lines_record_words(WIDE);
-  constexpr int kBatch = 8;
   auto div_s = [&](int x) -> int { return (int)(__umul24((uint32_t)x, invS) >> 16); };
   auto mul_s = [&](int x) -> int { return (int)__umul24((uint32_t)x, (uint32_t)S); };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1742,6 +1741,15 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
   const int C = S * S;
   const int T = a.T, Tt = a.Tt;
   const bool mc = a.mc != 0;
+  // what this launch needs at all (uniform): the kernel is a chain of memory round trips and little else, so every table that
+  // is not read and every pass that is not walked is time (ts_is_won in multi-colour mode compares two arrays and stops there)
+  const bool stepping = a.op == OP_STEP;                                        // some board may slide
+  const bool want_valid = EXTRAS && (a.valid != nullptr || a.valid4 != nullptr);
+  const bool want_reward = EXTRAS && a.reward != nullptr;
+  const bool need_rec = stepping || want_valid;                                 // the record's obstacle lines
+  const bool want_won = stepping || a.flags != nullptr;                         // (ts_valid_moves / ts_reward ask for no flags)
+  const bool need_rows = (!mc && want_won) || want_valid;                       // post-move tiles by row (set win, legality)
+  const bool need_tgt = Tt > 0 && ((mc && want_won) || want_reward);            // target cells in index order
 
   // lane-private columns: element `line` of this lane's array X is X[line * 64]
   uint32_t *col = reinterpret_cast<uint32_t *>(smem + (size_t)wave * a.lds_wave_bytes) + lane;
@@ -1750,28 +1758,46 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
   uint32_t *occ = lnC + NLN * kWave;                // S <= 16: pre-move tiles along the move's lines (low half) | post-move tiles by
   uint32_t *nrw = occ + (WIDE ? NLN * kWave : 0);   //          row (high half); above: two arrays
 
-  // ---- loads: the record's obstacle lines (and, single colour, its target rows), 16 bytes at a time ----
-  const uint4 *rec = reinterpret_cast<const uint4 *>(a.lines + (size_t)nl * REC);
+  // ---- ONE round trip for everything that does not depend on another load: the record's obstacle lines (16 bytes at a time),
+  //      the step's inputs, the first kBatch cells and targets.  The cells are read from `pos` before the board's `done` byte is
+  //      known; the boards that turn out to reset in place read their level's cells afterwards ----
+  const cell_t *g_pos = reinterpret_cast<const cell_t *>(a.pos) + nl;
+  const cell_t *g_init = reinterpret_cast<const cell_t *>(a.init) + nl;
+  const cell_t *g_tgt = reinterpret_cast<const cell_t *>(a.tgt) + nl;
+  const cell_t *first = a.op == OP_RESET ? g_init : g_pos;
+  int pf[kBatch], tf[kBatch];
+#pragma unroll
+  for (int k = 0; k < kBatch; ++k) {  // (a slot beyond the board's tiles reads row 0 again: a branch per load costs more than the load)
+    pf[k] = T > 0 ? (int)first[(int64_t)(k < T ? k : 0) * N] : 0;
+    tf[k] = need_tgt ? (int)g_tgt[(int64_t)(k < Tt ? k : 0) * N] : 0;
+  }
   constexpr int kQ = (WIDE ? 64 : 16) / 4;  // quads of obstacle words
   uint4 q[kQ];
+  if (need_rec) {
+    const uint4 *rec = reinterpret_cast<const uint4 *>(a.lines + (size_t)nl * REC);
 #pragma unroll
-  for (int i = 0; i < kQ; ++i) q[i] = rec[i];
+    for (int i = 0; i < kQ; ++i) q[i] = rec[i];
+  }
   uint32_t action = 0, done_in = 0;
   int32_t sc = 0;
-  if (a.op == OP_STEP) {  // uniform
+  if (stepping) {
     done_in = a.done[nl];
     sc = a.step_count[nl];
     action = a.actions[nl];
   }
+  if (need_rec) {
 #pragma unroll
-  for (int i = 0; i < kQ; ++i) {
-    uint32_t *dst = (WIDE && i >= 8 ? lnC + (i - 8) * 4 * kWave : lnR + i * 4 * kWave);
-    dst[0] = q[i].x, dst[kWave] = q[i].y, dst[2 * kWave] = q[i].z, dst[3 * kWave] = q[i].w;
+    for (int i = 0; i < kQ; ++i) {
+      uint32_t *dst = (WIDE && i >= 8 ? lnC + (i - 8) * 4 * kWave : lnR + i * 4 * kWave);
+      dst[0] = q[i].x, dst[kWave] = q[i].y, dst[2 * kWave] = q[i].z, dst[3 * kWave] = q[i].w;
+    }
   }
+  if (stepping || need_rows) {
 #pragma unroll
-  for (int i = 0; i < NLN; ++i) {
-    occ[i * kWave] = 0u;
-    if constexpr (WIDE) nrw[i * kWave] = 0u;
+    for (int i = 0; i < NLN; ++i) {
+      occ[i * kWave] = 0u;
+      if constexpr (WIDE) nrw[i * kWave] = 0u;
+    }
   }
 
   int kind;  // 0 = slide, 1 = leave untouched, 2 = reset to the level's initial cells
@@ -1787,9 +1813,14 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
   }
   const bool slide = kind == 0;
   const bool vert = (action & 2u) == 0, neg = (action & 1u) == 0;
-  const cell_t *src = reinterpret_cast<const cell_t *>(kind == 2 ? a.init : a.pos) + nl;  // per lane: boards that reset read the level
-  const cell_t *g_tgt = reinterpret_cast<const cell_t *>(a.tgt) + nl;
+  const cell_t *src = kind == 2 ? g_init : g_pos;  // per lane: boards that reset read the level
   cell_t *pos_out = reinterpret_cast<cell_t *>(a.pos) + nl;
+  if (stepping && T > 0 && __ballot(kind == 2) != 0) {  // boards that reset in place: the first cells again, from the level
+    if (kind == 2) {
+#pragma unroll
+      for (int k = 0; k < kBatch; ++k) pf[k] = (int)g_init[(int64_t)(k < T ? k : 0) * N];
+    }
+  }
   wave_sync();
 
   // ---- pre-move occupancy of the lines the move runs along (state.py:137-144 sorts by them) ----
@@ -1797,7 +1828,7 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
     for (int t0 = 0; t0 < T; t0 += kBatch) {
       int p[kBatch];
 #pragma unroll
-      for (int k = 0; k < kBatch; ++k) p[k] = (int)src[(int64_t)(t0 + k < T ? t0 + k : 0) * N];
+      for (int k = 0; k < kBatch; ++k) p[k] = t0 == 0 ? pf[k] : (int)src[(int64_t)(t0 + k < T ? t0 + k : 0) * N];
 #pragma unroll
       for (int k = 0; k < kBatch; ++k) {
         const int pp = min(p[k], C - 1);  // clamp: malformed ids stay in-board
@@ -1809,7 +1840,6 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
   }
 
   // ---- slide (state.py:120-170), flags' ingredients, post-move rows, reward ----
-  const bool need_rows = !mc || (EXTRAS && (a.valid != nullptr || a.valid4 != nullptr));
   const bool store_pos = live && kind != 1;
   bool same = true, ordered = true;
   int rsum = 0;
@@ -1817,35 +1847,41 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
     int p[kBatch], tg[kBatch];
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
-      p[k] = (int)src[(int64_t)(t0 + k < T ? t0 + k : 0) * N];
-      tg[k] = Tt > 0 ? (int)g_tgt[(int64_t)(t0 + k < Tt ? t0 + k : 0) * N] : 0;
+      p[k] = t0 == 0 ? pf[k] : (int)src[(int64_t)(t0 + k < T ? t0 + k : 0) * N];
+      tg[k] = t0 == 0 ? tf[k] : (need_tgt ? (int)g_tgt[(int64_t)(t0 + k < Tt ? t0 + k : 0) * N] : 0);
     }
 #pragma unroll
     for (int k = 0; k < kBatch; ++k) {
       const int t = t0 + k;
       if (t < T) {  // uniform
         const int pp = min(p[k], C - 1), tt = min(tg[k], C - 1);
-        const int r0 = div_s(pp), c0 = pp - mul_s(r0);
-        const int line = vert ? c0 : r0, x0 = vert ? r0 : c0;
-        uint32_t O = occ[line * kWave], B;
-        if constexpr (WIDE) {
-          B = vert ? lnC[line * kWave] : lnR[line * kWave];
-        } else {
-          const uint32_t w = lnR[line * kWave];
-          B = vert ? (w >> 16) : (w & 0xffffu);
-          O &= 0xffffu;
+        int qq = pp, r = 0, c = 0;
+        if (stepping || need_rows || want_reward) {  // uniform
+          const int r0 = div_s(pp), c0 = pp - mul_s(r0);
+          r = r0, c = c0;
+          if (stepping) {  // uniform
+            const int line = vert ? c0 : r0, x0 = vert ? r0 : c0;
+            uint32_t O = occ[line * kWave], B;
+            if constexpr (WIDE) {
+              B = vert ? lnC[line * kWave] : lnR[line * kWave];
+            } else {
+              const uint32_t w = lnR[line * kWave];
+              B = vert ? (w >> 16) : (w & 0xffffu);
+              O &= 0xffffu;
+            }
+            const int x1 = ts::slide_line(x0, B, O, S, neg);
+            const int x = slide ? x1 : x0;
+            r = vert ? x : r0, c = vert ? c0 : x;
+            qq = mul_s(r) + c;
+          }
         }
-        const int x1 = ts::slide_line(x0, B, O, S, neg);
-        const int x = slide ? x1 : x0;
-        const int r = vert ? x : r0, c = vert ? c0 : x;
-        const int qq = mul_s(r) + c;
         same &= qq == pp;
         const bool hasG = t < Tt;
         ordered &= (qq == tt) | !hasG;
         if (need_rows) atomicOr(&nrw[r * kWave], (WIDE ? 1u : 0x10000u) << c);
         if (store_pos) pos_out[(int64_t)t * N] = (cell_t)qq;
         if constexpr (EXTRAS) {
-          if (a.reward && hasG) {  // build-defined Manhattan reward, multi colour (single colour keeps k_lines)
+          if (want_reward && hasG) {  // build-defined Manhattan reward, multi colour (single colour keeps k_lines)
             const int tr = div_s(tt), tc = tt - mul_s(tr);
             rsum += abs(r - tr) + abs(c - tc);
           }
@@ -1862,8 +1898,10 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
     won = ordered && T == Tt;  // state.py:183-184
   } else {                     // state.py:185-186: the SETS of tile and target cells are equal - row masks against the record's Tm
     won = true;
-    const uint32_t *tm = a.lines + (size_t)nl * REC + (WIDE ? 64 : 16);
-    for (int r = 0; r < S; ++r) won &= tiles_row(r) == (WIDE ? tm[r] : (tm[r] & 0xffffu));
+    if (want_won) {
+      const uint32_t *tm = a.lines + (size_t)nl * REC + (WIDE ? 64 : 16);
+      for (int r = 0; r < S; ++r) won &= tiles_row(r) == (WIDE ? tm[r] : (tm[r] & 0xffffu));
+    }
   }
   if (a.op == OP_OBSERVE && won) flags |= TS_FLAG_IS_WON;
   if (slide) {
@@ -1886,7 +1924,7 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
   if constexpr (EXTRAS) {
     // ---- legality mask of the post-move board (environment.py:149-171): a move changes the board iff some tile has a free
     //      neighbour cell in its direction (ts_core.h: valid_mask) - row by row on the masks ----
-    if (a.valid || a.valid4) {
+    if (want_valid) {
       uint32_t vm = 0;
       const uint32_t last = 1u << (S - 1);
       uint32_t above = 0xffffffffu;  // "row -1" is full: nothing moves up out of row 0
@@ -1903,7 +1941,7 @@ __global__ __launch_bounds__(256) void k_state(const KArgs a, const int S, const
       if (live && a.valid) a.valid[n] = (uint8_t)vm;
       if (live && a.valid4) reinterpret_cast<uint32_t *>(a.valid4)[n] = spread_valid(vm);
     }
-    if (a.reward && live) a.reward[n] = -rsum;
+    if (want_reward && live) a.reward[n] = -rsum;
   }
 }
 
@@ -2223,6 +2261,70 @@ __global__ void k_expand_tail(const uint8_t *src, float *dst) {
   if (threadIdx.x == 0) *dst = (float)*src;
 }
 
+// ------------------------------------------------------------------------------------------
+// Multi-GPU hand-off (include/tiler_slider.h, "multi-GPU hand-off"): the per-rank message [cells | flags | reward | steps].
+// Pure byte movement of a few MB (1M 4x4 boards: 3 MiB), launch-bound: ONE launch replaces the three or four strided copies a
+// binder would otherwise enqueue per step on each side.  blockIdx.y = row of the message (a tile's cells, the flags, the
+// rewards, the counters), blockIdx.z = the sending rank (unpack); 16 bytes per lane where source and destination rows are
+// 16-byte aligned (wave-uniform test), single bytes otherwise (odd shard sizes).
+// ------------------------------------------------------------------------------------------
+struct HandoffArgs {
+  const unsigned char *pos, *flags, *reward, *steps;  // pack: sources; unpack: destinations (cast away const there)
+  unsigned char *msg;                                 // pack: destination; unpack: the received messages
+  const int64_t *offsets;                             // unpack: first board of every rank in the gathered batch (world + 1 entries)
+  int64_t N, nm, stride;                              // boards of this shard (pack), padded shard size, bytes between messages
+  int64_t off_flags, off_reward, off_steps;           // segment offsets inside a message (-1: absent)
+  int32_t T, cb, world, cells;                        // tile rows, bytes per cell id, ranks, message carries cells
+};
+
+__device__ __forceinline__ void copy_row(const unsigned char *src, unsigned char *dst, int64_t nbytes) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    const int64_t quads = nbytes >> 4;
+    for (int64_t i = tid; i < quads; i += nthreads) reinterpret_cast<uint4 *>(dst)[i] = reinterpret_cast<const uint4 *>(src)[i];
+    for (int64_t i = (quads << 4) + tid; i < nbytes; i += nthreads) dst[i] = src[i];
+  } else {
+    for (int64_t i = tid; i < nbytes; i += nthreads) dst[i] = src[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack_handoff(const HandoffArgs h) {
+  int row = (int)blockIdx.y;
+  const int cell_rows = h.cells ? h.T : 0;
+  if (row < cell_rows) {
+    copy_row(h.pos + (int64_t)row * h.N * h.cb, h.msg + (int64_t)row * h.nm * h.cb, h.N * h.cb);
+    return;
+  }
+  row -= cell_rows;
+  if (row == 0) {
+    copy_row(h.flags, h.msg + h.off_flags, h.N);
+  } else if (row == 1 && h.off_reward >= 0) {
+    copy_row(h.reward, h.msg + h.off_reward, h.N * 4);
+  } else {
+    copy_row(h.steps, h.msg + h.off_steps, h.N * 4);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_unpack_handoff(const HandoffArgs h) {
+  int row = (int)blockIdx.y;
+  const int r = (int)blockIdx.z;
+  const unsigned char *m = h.msg + (int64_t)r * h.stride;
+  const int cell_rows = h.cells ? h.T : 0;
+  if (row < cell_rows) {  // rank-major [world][T][nm] -> the SoA rows of one batch of world * nm boards (padding boards included)
+    copy_row(m + (int64_t)row * h.nm * h.cb, const_cast<unsigned char *>(h.pos) + ((int64_t)row * h.world + r) * h.nm * h.cb, h.nm * h.cb);
+    return;
+  }
+  row -= cell_rows;
+  const int64_t lo = h.offsets[r], cnt = h.offsets[r + 1] - lo;
+  if (row == 0) {
+    copy_row(m + h.off_flags, const_cast<unsigned char *>(h.flags) + lo, cnt);
+  } else if (row == 1 && h.off_reward >= 0) {
+    copy_row(m + h.off_reward, const_cast<unsigned char *>(h.reward) + lo * 4, cnt * 4);
+  } else {
+    copy_row(m + h.off_steps, const_cast<unsigned char *>(h.steps) + lo * 4, cnt * 4);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_fill_actions(uint8_t *actions, int64_t N, uint64_t key, int64_t board_offset) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N) actions[n] = (uint8_t)(ts::mix64(key + (uint64_t)(board_offset + n) * ts::kDrawMul) >> 62);
@@ -2440,7 +2542,7 @@ constexpr uint64_t kEdgeMinChunk = 8 * KiB;
 // ... and their absolute cap per launch, 1 KiB per edge instruction and chunk (r04_large_batch_edges*.log, r04_knee_probe.log: beyond
 // ~150 MB of cached edge bytes the kernels that read much state per board lose half their rate - cfg4's shape at 1.4 GB 401.8 us
 // with both edges, 214.4 with the last only, 212.0 with none); beyond 1 GiB per launch a little less is tolerated (24x24 at 2.1 GB)
-constexpr uint64_t kEdgeCapBytes = 152 * MiB, kEdgeCapBytesBeyond = 128 * MiB, kEdgeCapSwitch = 1024 * MiB, kEdgeBytesPerSite = 1 * KiB;
+constexpr uint64_t kEdgeCapBytes = 152 * MiB, kEdgeCapBytesBeyond = 128 * MiB, kEdgeCapOneBeyond = 112 * MiB, kEdgeCapSwitch = 1024 * MiB, kEdgeBytesPerSite = 1 * KiB;
 constexpr int kEdgeCapStateBytes = 20;  // k_small forms with fewer bytes of state per board keep both edges at any size (4x4 / 5x5 with two
                                         // tiles at 1 GB: both 149 / 146 us, one 154 - 166, none 173 / 176; r04_large_batch_edges_small_boards*.log)
 // Block -> board-range mapping: pieces of P one-wave blocks per XCD (r04_contig_sweep.log, r04_piece_by_shape.log; eighths -> best piece:
@@ -2470,6 +2572,8 @@ constexpr int lookup(const ByChunk *rows, uint64_t chunk) {
   while (chunk < rows->min_chunk) ++rows;
   return rows->value;
 }
+// k_state: eight cells (and targets) in flight per lane up to this many tiles, sixteen above (r05_state_only_ab.log)
+constexpr int kStateBatch8MaxT = 8;
 }  // namespace policy
 Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy, uint64_t chunk, int tiles) {
 #if defined(TS_RES_ALWAYS)  // experiment: apply the forced residency to cache-resident launches too
@@ -2513,7 +2617,10 @@ uint32_t edge_policy_capped(uint64_t obs_chunk, uint64_t edge_instruction_sites,
   uint32_t e = edge_policy(obs_chunk);
   const uint64_t kCap = obs_chunk * edge_instruction_sites > policy::kEdgeCapSwitch ? policy::kEdgeCapBytesBeyond : policy::kEdgeCapBytes;
   if (e == 3u && 2u * policy::kEdgeBytesPerSite * edge_instruction_sites > kCap) e = keep_first ? 1u : 2u;  // one edge instruction only
-  if (e != 0u && e != 3u && policy::kEdgeBytesPerSite * edge_instruction_sites > kCap) e = 0u;
+  // ... and a single edge beyond 1 GiB per launch pays up to ~111 MiB of it (16x16 / 8x8 with 20 tiles at 1.4 GB: 219 / 232 us against
+  // 243 with none) and costs from 126 MiB on (13x13 / 3 tiles at 2.1 GB: 416.7 us against 323.6 with none, profiles/r05_asymptote_probe.log)
+  const uint64_t kCapOne = obs_chunk * edge_instruction_sites > policy::kEdgeCapSwitch ? policy::kEdgeCapOneBeyond : policy::kEdgeCapBytes;
+  if (e != 0u && e != 3u && policy::kEdgeBytesPerSite * edge_instruction_sites > kCapOne) e = 0u;
   return e;
 }
 
@@ -2787,7 +2894,13 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
       const int waves = wide ? 2 : 4;
       const int64_t blocks = (d->n_boards + (int64_t)waves * kWave - 1) / ((int64_t)waves * kWave);
       if (blocks > 0x7fffffffLL) return TS_ERR_LIMIT;
-      plan.lines = wide ? (extras ? k_state<true, true> : k_state<true, false>) : (extras ? k_state<false, true> : k_state<false, false>);
+      // cells (and targets) a lane has in flight per round trip: 8 up to 8 tiles - the slots beyond a board's tiles are loads like
+      // any other (9x9 / 4 tiles, 1M boards: ts_is_won 15.7 us with 16 slots, 8.3 with 8) - else 16 (15x15 / 32 tiles: the step 24.7
+      // against 28.4 us; 32 slots cost a wave per SIMD and are slower everywhere): profiles/r05_state_only_ab.log
+      const bool b8 = (T > Tt ? T : Tt) <= policy::kStateBatch8MaxT;
+      plan.lines = wide ? (extras ? (b8 ? k_state<true, true, 8> : k_state<true, true, 16>) : (b8 ? k_state<true, false, 8> : k_state<true, false, 16>))
+                        : (extras ? (b8 ? k_state<false, true, 8> : k_state<false, true, 16>) : (b8 ? k_state<false, false, 8> : k_state<false, false, 16>));
+      plan.tiles_per_lane = b8 ? 8 : 16;
       plan.inv_s = (uint32_t)((65536 + S - 1) / S);
       plan.blocks = (uint32_t)blocks, plan.threads = (uint32_t)(waves * kWave);
       plan.lds_request = plan.lds_used = (size_t)waves * a.lds_wave_bytes;
@@ -3057,6 +3170,79 @@ int32_t ts_expand_u8(const uint8_t *src, float *dst, int64_t count, void *stream
   return finish_launch();
 }
 
+int64_t ts_handoff_layout(const ts_dims *dims, int64_t n_padded, uint32_t fields, int64_t offsets_out[4]) {
+  const int32_t rc = check_dims(dims);
+  if (rc) return rc;
+  if (n_padded < dims->n_boards || (fields & ~(TS_HANDOFF_CELLS | TS_HANDOFF_REWARD | TS_HANDOFF_STEP_COUNT))) return TS_ERR_ARG;
+  auto a16 = [](int64_t x) { return (x + 15) & ~(int64_t)15; };
+  int64_t at = 0, off[4] = {-1, -1, -1, -1};
+  if (fields & TS_HANDOFF_CELLS) off[0] = 0, at = a16((int64_t)dims->n_tiles * n_padded * (dims->size > 16 ? 2 : 1));
+  off[1] = at, at += a16(n_padded);
+  if (fields & TS_HANDOFF_REWARD) off[2] = at, at += a16(4 * n_padded);
+  if (fields & TS_HANDOFF_STEP_COUNT) off[3] = at, at += a16(4 * n_padded);
+  if (offsets_out)
+    for (int i = 0; i < 4; ++i) offsets_out[i] = off[i];
+  return at;
+}
+
+static int32_t handoff_grid(const HandoffArgs &h, int64_t longest_row_bytes, dim3 *grid, int ranks) {
+  const int rows = (h.cells ? h.T : 0) + 1 + (h.off_reward >= 0 ? 1 : 0) + (h.off_steps >= 0 ? 1 : 0);
+  int64_t bx = (longest_row_bytes + 256 * 16 - 1) / (256 * 16);  // 16 bytes per lane, grid-stride beyond 1024 blocks per row
+  bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+  if (ranks > 65535) return TS_ERR_LIMIT;
+  *grid = dim3((uint32_t)bx, (uint32_t)rows, (uint32_t)ranks);
+  return TS_OK;
+}
+
+int32_t ts_pack_handoff(const ts_dims *dims, const ts_state *st, const uint8_t *flags, const int32_t *reward, int64_t n_padded,
+                        uint32_t fields, void *msg, void *stream) {
+  int64_t off[4];
+  const int64_t total = ts_handoff_layout(dims, n_padded, fields, off);
+  if (total < 0) return (int32_t)total;
+  if (dims->n_boards == 0) return TS_OK;
+  if (!st || !flags || !msg || ((fields & TS_HANDOFF_CELLS) && dims->n_tiles && !st->pos) || ((fields & TS_HANDOFF_REWARD) && !reward) ||
+      ((fields & TS_HANDOFF_STEP_COUNT) && !st->step_count))
+    return TS_ERR_NULL;
+  if ((uintptr_t)msg & 15u) return TS_ERR_ARG;
+  HandoffArgs h = {};
+  h.pos = (const unsigned char *)st->pos, h.flags = flags, h.reward = (const unsigned char *)reward, h.steps = (const unsigned char *)st->step_count;
+  h.msg = (unsigned char *)msg;
+  h.N = dims->n_boards, h.nm = n_padded;
+  h.off_flags = off[1], h.off_reward = off[2], h.off_steps = off[3];
+  h.T = dims->n_tiles, h.cb = dims->size > 16 ? 2 : 1, h.world = 1, h.cells = (fields & TS_HANDOFF_CELLS) ? 1 : 0;
+  dim3 grid;
+  if (const int32_t rc = handoff_grid(h, h.N * 4, &grid, 1)) return rc;
+  hipLaunchKernelGGL(k_pack_handoff, grid, dim3(256), 0, (hipStream_t)stream, h);
+  return finish_launch();
+}
+
+int32_t ts_unpack_handoff(const ts_dims *dims, int64_t n_padded, uint32_t fields, int32_t world, const int64_t *offsets,
+                          const void *msgs, int64_t msg_stride, void *pos_all, uint8_t *flags_all, int32_t *reward_all,
+                          int32_t *steps_all, void *stream) {
+  if (!dims) return TS_ERR_NULL;
+  ts_dims d = *dims;
+  d.n_boards = 0;  // the shards' sizes come from `offsets`
+  int64_t off[4];
+  const int64_t total = ts_handoff_layout(&d, n_padded, fields, off);
+  if (total < 0) return (int32_t)total;
+  if (world < 1 || msg_stride < total) return TS_ERR_ARG;
+  if (n_padded == 0) return TS_OK;
+  if (!offsets || !msgs || !flags_all || ((fields & TS_HANDOFF_CELLS) && dims->n_tiles && !pos_all) || ((fields & TS_HANDOFF_REWARD) && !reward_all) ||
+      ((fields & TS_HANDOFF_STEP_COUNT) && !steps_all))
+    return TS_ERR_NULL;
+  HandoffArgs h = {};
+  h.pos = (const unsigned char *)pos_all, h.flags = flags_all, h.reward = (const unsigned char *)reward_all, h.steps = (const unsigned char *)steps_all;
+  h.msg = (unsigned char *)const_cast<void *>(msgs);
+  h.offsets = offsets;
+  h.nm = n_padded, h.stride = msg_stride;
+  h.off_flags = off[1], h.off_reward = off[2], h.off_steps = off[3];
+  h.T = dims->n_tiles, h.cb = dims->size > 16 ? 2 : 1, h.world = world, h.cells = (fields & TS_HANDOFF_CELLS) ? 1 : 0;
+  dim3 grid;
+  if (const int32_t rc = handoff_grid(h, n_padded * 4, &grid, world)) return rc;
+  hipLaunchKernelGGL(k_unpack_handoff, grid, dim3(256), 0, (hipStream_t)stream, h);
+  return finish_launch();
+}
+
 int32_t ts_encode_onehot(const ts_dims *dims, const ts_state *st, float *onehot, void *stream) {
   const int32_t rc = check_dims(dims);
   if (rc) return rc;
@@ -3130,7 +3316,7 @@ int32_t ts_describe_launch(const ts_dims *dims, uint32_t op, uint32_t outputs_ma
     case TS_KERNEL_MULTI: snprintf(desc->name, sizeof desc->name, "k_multi<%d, %d, %s, %d>", S, plan.tiles_per_lane, tf[plan.extras], plan.boards_per_lane); break;
     case TS_KERNEL_DEAL: snprintf(desc->name, sizeof desc->name, "k_deal<%d, %d, %d, %s, %s>", S, plan.lanes_per_board, plan.tiles_per_lane, tf[plan.extras], tf[k.nt]); break;
     case TS_KERNEL_LINES: snprintf(desc->name, sizeof desc->name, "k_lines<%s, %d, %d, %s, %s>", tf[plan.wide], plan.lanes_per_board, plan.tiles_per_lane, tf[k.nt], tf[plan.extras]); break;
-    case TS_KERNEL_STATE: snprintf(desc->name, sizeof desc->name, "k_state<%s, %s>", tf[plan.wide], tf[plan.extras]); break;
+    case TS_KERNEL_STATE: snprintf(desc->name, sizeof desc->name, "k_state<%s, %s, %d>", tf[plan.wide], tf[plan.extras], plan.tiles_per_lane); break;
     default: break;
   }
   return TS_OK;

@@ -40,7 +40,10 @@ What the collective reads while the next step runs (the buffers that are double-
     (async gathers of a single-buffered environment are refused);
   * cell ids, flags, reward, step counters: single-buffered state that step k+1 rewrites in place, so
     every gather first SNAPSHOTS them, stream-ordered behind step k, into one of two send slots
-    (T + 1 bytes per board: 3 MiB at 1M 4x4 boards) and the collective reads the slot.
+    (T + 1 bytes per board: 3 MiB at 1M 4x4 boards) and the collective reads the slot.  The snapshot is ONE launch
+    (ts_pack_handoff: the message layout of include/tiler_slider.h, "multi-GPU hand-off"), and so is its counterpart on the
+    receiving rank (ts_unpack_handoff: the cell rows of one batch of all boards for ts_encode, flags / reward / counters with
+    the shards' padding dropped); on CPU tensors (the gloo tests) the same layout is written by torch copies.
 The RECEIVE side (obs_all and the padded / byte / cell-id images it is assembled from) is single-buffered, and all three
 forms assemble into the same observation image: ONE gather in flight per gatherer.  Wait for gather k before issuing gather
 k+1 - issuing a second one while a handle is unfinished raises RuntimeError instead of letting collective k+1 overwrite what
@@ -58,6 +61,7 @@ tests, which inject an encoder because the HIP library needs a GPU.  `all_gather
 the collective itself (tests run several ranks as threads of one process on one GPU with them).
 """
 import ctypes as C
+from collections.abc import Mapping
 from types import SimpleNamespace
 
 import torch
@@ -94,31 +98,146 @@ def _hip_expand(env, src_u8, dst_f32):
 def _hip_encode(env, shard):
     """ts_encode of one gathered shard: `shard` has pos [T, n], tgt [Tt, n], blk [W, n],
     lines [n, words] or None (all contiguous, n = shard.n_boards) and out [n, S, S, 3]."""
-    from . import _cabi
-    dims = _cabi.Dims(shard.n_boards, env.size, env.n_tiles, env.n_targets, int(env.multi_color), env.max_steps, 0)
-    st = _cabi.State(shard.pos.data_ptr() if shard.pos.numel() else None, None,
-                     shard.tgt.data_ptr() if shard.tgt.numel() else None, shard.blk.data_ptr(), None, None,
-                     shard.lines.data_ptr() if shard.lines is not None and shard.lines.numel() else None)
-    env._call("ts_encode", C.byref(dims), C.byref(st), shard.out.data_ptr())
+    c = getattr(shard, "_c", None)
+    if c is None:  # the gatherer hands over the same job every step: its C structs are built once
+        from . import _cabi
+        dims = _cabi.Dims(shard.n_boards, env.size, env.n_tiles, env.n_targets, int(env.multi_color), env.max_steps, 0)
+        st = _cabi.State(shard.pos.data_ptr() if shard.pos.numel() else None, None,
+                         shard.tgt.data_ptr() if shard.tgt.numel() else None, shard.blk.data_ptr(), None, None,
+                         shard.lines.data_ptr() if shard.lines is not None and shard.lines.numel() else None)
+        c = shard._c = (dims, st, C.byref(dims), C.byref(st), shard.out.data_ptr())
+    env._call("ts_encode", c[2], c[3], c[4])
+
+
+HANDOFF_CELLS, HANDOFF_REWARD, HANDOFF_STEP_COUNT = 0x1, 0x2, 0x4  # TS_HANDOFF_* of include/tiler_slider.h
+
+
+def handoff_layout(n_tiles, cell_bytes, n_padded, fields):
+    """ts_handoff_layout restated (this module runs on gloo without the library; tests/test_cabi_and_host_logic.py holds the
+    two against each other): ([cells, flags, reward, steps] byte offsets, -1 = absent; message bytes).  16-byte segments."""
+    a16 = lambda x: (x + 15) & ~15
+    off, at = [-1, -1, -1, -1], 0
+    if fields & HANDOFF_CELLS:
+        off[0], at = 0, a16(n_tiles * n_padded * cell_bytes)
+    off[1], at = at, at + a16(n_padded)
+    if fields & HANDOFF_REWARD:
+        off[2], at = at, at + a16(4 * n_padded)
+    if fields & HANDOFF_STEP_COUNT:
+        off[3], at = at, at + a16(4 * n_padded)
+    return off, at
+
+
+def _torch_pack(env, msg, n_padded, fields):
+    """ts_pack_handoff on CPU tensors (gloo): the same bytes, written by torch copies."""
+    n, T = env.num_envs, env._pos.shape[0]
+    cb = env._pos.element_size()
+    off, _ = handoff_layout(T, cb, n_padded, fields)
+    if fields & HANDOFF_CELLS and T:
+        msg[:T * n_padded * cb].view(env._pos.dtype).view(T, n_padded)[:, :n].copy_(env._pos)
+    msg[off[1]:off[1] + n].copy_(env._flags)
+    if fields & HANDOFF_REWARD:
+        msg[off[2]:off[2] + 4 * n_padded].view(torch.int32)[:n].copy_(env._reward)
+    if fields & HANDOFF_STEP_COUNT:
+        msg[off[3]:off[3] + 4 * n_padded].view(torch.int32)[:n].copy_(env._step_count)
+
+
+def _hip_pack(env, msg, n_padded, fields):
+    env._call("ts_pack_handoff", C.byref(env._dims), C.byref(env._state), env._flags.data_ptr(),
+              env._reward.data_ptr() if fields & HANDOFF_REWARD else None, n_padded, fields, msg.data_ptr())
+
+
+def _torch_unpack(g, recv, fields):
+    """ts_unpack_handoff on CPU tensors (gloo).  recv: uint8 [world, message bytes]."""
+    env, nm, W = g.env, g.nmax, g.world
+    T, cb = env._pos.shape[0], env._pos.element_size()
+    off, _ = handoff_layout(T, cb, nm, fields)
+    if fields & HANDOFF_CELLS and T:
+        cells = recv[:, :T * nm * cb].view(env._pos.dtype).view(W, T, nm)
+        g.pos_flat.view(T, W, nm).copy_(cells.permute(1, 0, 2))
+    words = lambda o: recv[:, o:o + 4 * nm].view(torch.int32)  # [world, nmax] int32 (16-byte segments)
+    for r in range(W):
+        lo, c = g.offsets[r], g.counts[r]
+        g.flags_all[lo:lo + c].copy_(recv[r, off[1]:off[1] + c])
+        if fields & HANDOFF_REWARD:
+            g.reward_all[lo:lo + c].copy_(words(off[2])[r, :c])
+        if fields & HANDOFF_STEP_COUNT:
+            g.step_count_all[lo:lo + c].copy_(words(off[3])[r, :c])
+
+
+def _hip_unpack(g, recv, fields):
+    env = g.env
+    env._call("ts_unpack_handoff", C.byref(env._dims), g.nmax, fields, g.world, g._offsets_dev.data_ptr(), recv.data_ptr(), recv.shape[1],
+              g.pos_flat.data_ptr() if fields & HANDOFF_CELLS and g.pos_flat.numel() else None, g.flags_all.data_ptr(),
+              g.reward_all.data_ptr() if fields & HANDOFF_REWARD else None,
+              g.step_count_all.data_ptr() if fields & HANDOFF_STEP_COUNT else None)
+
+
+class HandoffInfo(Mapping):
+    """What a hand-off delivers besides the observations, for ALL boards: `flags` (the step's TS_FLAG_* byte), `reward` and
+    `step_count` (when the environment / the gatherer carry them) as gathered, and `done`, `is_won`, `invalid_move`, `success`,
+    `timeout` decoded from the flag byte when asked for (nothing is launched for a key nobody reads).  Views of the gatherer's
+    receive buffers: the next hand-off overwrites them."""
+
+    _BITS = {"is_won": _FLAG_IS_WON, "invalid_move": _FLAG_INVALID_MOVE, "success": _FLAG_SUCCESS, "timeout": _FLAG_TIMEOUT}
+
+    def __init__(self, flags, reward=None, step_count=None):
+        self._t = {"flags": flags}
+        if reward is not None:
+            self._t["reward"] = reward
+        if step_count is not None:
+            self._t["step_count"] = step_count  # AFTER the step's increment (the environment's counter; StepInfo subtracts it back)
+
+    def __getitem__(self, key):
+        if key in self._t:
+            return self._t[key]
+        if key == "done":
+            return done_from_flags(self._t["flags"])
+        if key in self._BITS:
+            return (self._t["flags"] & self._BITS[key]) != 0
+        raise KeyError(key)
+
+    def __iter__(self):
+        yield from ("flags", "done", "is_won", "invalid_move", "success", "timeout")
+        yield from (k for k in ("reward", "step_count") if k in self._t)
+
+    def __len__(self):
+        return 5 + len(self._t)
 
 
 class GatherHandle:
     """A hand-off in flight; wait() completes it (stream-ordered on CUDA/ROCm) and returns the assembled observations
-    (None on the ranks that are not the root of a gather-to-root); `info` then holds the gathered flags / done / reward."""
+    (None on the ranks that are not the root of a gather-to-root); `info` then holds the gathered flags / done / reward.
 
-    def __init__(self, work, finish):
-        self._work, self._finish, self._result, self.info = work, finish, None, None
+    The compact form completes in two phases, for a learner that pipelines: receive() makes the current stream wait for the
+    collective and unpacks the message (cell rows, flags, reward: `info` is valid from here on) - the receive image is then free,
+    and the NEXT gather_compact_and_encode may be issued before this handle's wait(), whose ts_encode of ALL boards (the
+    learner's long launch: 0.24 ms for 8M 4x4 boards) then runs beside that collective instead of in front of it."""
+
+    def __init__(self, work, receive, finish, two_phase=False):
+        self._work, self._receive, self._finish, self._result, self.info = work, receive, finish, None, None
+        self.two_phase = two_phase
+
+    @property
+    def received(self):
+        return self._receive is None
 
     @property
     def finished(self):
         return self._finish is None
 
-    def wait(self):
-        if self._finish is not None:
+    def receive(self):
+        if self._receive is not None:
             for w in self._work:
                 if w is not None:
                     w.wait()
-            self._result, self.info = self._finish()
+            self.info = self._receive()
+            self._receive = None
+        return self.info
+
+    def wait(self):
+        if self._finish is not None:
+            self.receive()
+            self._result = self._finish()
             self._finish = None
         return self._result
 
@@ -132,6 +251,8 @@ class ObservationGatherer:
         self.env, self.world, self.group = env, int(world_size), group
         self.encode_fn = encode_fn or _hip_encode
         self.expand_fn = expand_fn or _hip_expand
+        on_gpu = env._pos.device.type == "cuda"  # CPU tensors: the gloo tests (they inject encode_fn / expand_fn too)
+        self._pack, self._unpack = (_hip_pack, _hip_unpack) if on_gpu else (_torch_pack, _torch_unpack)
         self._all_gather = all_gather_fn or self._dist_all_gather
         self._gather_to_root = gather_fn or self._dist_gather
         self.root = None if root is None else int(root)
@@ -170,22 +291,22 @@ class ObservationGatherer:
         self._send_pad = {}  # padded copies of this rank's buffers (only on ranks with n < nmax)
         self._pending = None  # the one gather that may be in flight (the receive side is single-buffered)
         self.info = None      # what the last finished hand-off delivered besides the observations
-        # ---- the per-step message besides the observations: [cell ids |] flags [| reward] [| step counters], every segment
-        # padded to a multiple of 4 bytes (int32 views).  Two send slots (see the module docstring), one receive image.
+        # ---- the per-step message besides the observations: [cell ids |] flags [| reward] [| step counters] (handoff_layout).
+        # Two send slots (see the module docstring), one receive image per form.
         T = env._pos.shape[0]
         self._cell_bytes = env._pos.element_size()
         self._has_reward = getattr(env, "_reward", None) is not None
         self._has_steps = bool(with_step_count)
-        a4 = lambda x: (x + 3) & ~3
-        self._seg_pos = a4(T * nm * self._cell_bytes)
-        self._seg_flags = a4(nm)
-        self._off_reward = self._seg_flags
-        self._off_steps = self._off_reward + (4 * nm if self._has_reward else 0)
-        self._info_bytes = self._off_steps + (4 * nm if self._has_steps else 0)
-        self._msg_send = [torch.zeros(self._seg_pos + self._info_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._info_fields = (HANDOFF_REWARD if self._has_reward else 0) | (HANDOFF_STEP_COUNT if self._has_steps else 0)
+        self._msg_bytes = handoff_layout(T, self._cell_bytes, nm, self._info_fields | HANDOFF_CELLS)[1]
+        self._info_bytes = handoff_layout(T, self._cell_bytes, nm, self._info_fields)[1]
+        self._msg_send = [torch.zeros(self._msg_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self._info_send = [torch.zeros(self._info_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]  # (the padding boards of a
+        #                   short shard are never written: each form keeps its own slots, so they stay zero)
         self._msg_slot = self._pad_slot = 0
-        self._msg_recv = torch.empty((W, self._seg_pos + self._info_bytes), dtype=torch.uint8, device=dev) if recv else None
+        self._msg_recv = torch.empty((W, self._msg_bytes), dtype=torch.uint8, device=dev) if recv else None
         self._info_recv = torch.empty((W, self._info_bytes), dtype=torch.uint8, device=dev) if recv else None  # observation forms
+        self._offsets_dev = torch.tensor(self.offsets + [self.total], dtype=torch.int64, device=dev) if recv else None
         self.pos_flat = torch.empty((T, W * nm), dtype=env._pos.dtype, device=dev) if recv else None  # SoA over all W * nmax boards
         self.flags_all = torch.empty(self.total, dtype=torch.uint8, device=dev) if recv else None
         self.reward_all = torch.empty(self.total, dtype=torch.int32, device=dev) if recv and self._has_reward else None
@@ -201,6 +322,10 @@ class ObservationGatherer:
             self._gather(la, self._padded_rows(lines, "lines"), False)
             self.lines_flat = la.view(W * nm, lines.shape[1]) if recv else None  # board-major records: rank-major is already flat
         self._send_pad.pop("lines", None)
+        self._encode_job = None
+        if recv:  # what gather_compact_and_encode hands to encode_fn every step: the gathered batch as ONE batch of W * nmax boards
+            self._encode_job = SimpleNamespace(n_boards=W * nm, pos=self.pos_flat, tgt=self.tgt_flat, blk=self.blk_flat,
+                                               out=self._padded_obs.view((-1,) + obs_shape), lines=self.lines_flat)
         info_b = nm * (1 + (4 if self._has_reward else 0) + (4 if self._has_steps else 0))
         self.bytes_per_step = {"obs_f32": nm * S * S * 12 + info_b,
                                "compact_state_then_encode": T * nm * self._cell_bytes + info_b,
@@ -261,64 +386,41 @@ class ObservationGatherer:
 
     # ------------------------------------------------------------------ flags / reward / step counters
     def _snapshot_message(self, with_pos):
-        """This rank's message of the step just taken, copied (stream-ordered behind that step) into the next send slot; returns
-        the bytes to send: the whole slot (cell ids + info, compact form) or its info part (observation forms)."""
-        env, n, nm = self.env, self.env.num_envs, self.nmax
-        msg = self._msg_send[self._msg_slot]
+        """This rank's message of the step just taken, written (stream-ordered behind that step, one launch) into the next send
+        slot; returns the bytes to send: cell ids + info (compact form) or the info alone (observation forms)."""
+        msg = (self._msg_send if with_pos else self._info_send)[self._msg_slot]
         self._msg_slot ^= 1
-        T = env._pos.shape[0]
-        if with_pos and T:
-            msg[:T * nm * self._cell_bytes].view(env._pos.dtype).view(T, nm)[:, :n].copy_(env._pos)
-        info = msg[self._seg_pos:]
-        info[:n].copy_(env._flags)
-        if self._has_reward:
-            info[self._off_reward:self._off_reward + 4 * nm].view(torch.int32)[:n].copy_(env._reward)
-        if self._has_steps:
-            info[self._off_steps:self._off_steps + 4 * nm].view(torch.int32)[:n].copy_(env._step_count)
-        return msg if with_pos else info
+        self._pack(self.env, msg, self.nmax, self._info_fields | (HANDOFF_CELLS if with_pos else 0))
+        return msg
 
-    def _unpack_info(self, recv_info):
-        """recv_info: uint8 [world, info_bytes] as received -> flags_all / reward_all / step_count_all (padding dropped) and the
-        info dict of the gathered batch."""
-        nm, W = self.nmax, self.world
-        words = lambda off: recv_info[:, off:off + 4 * nm].view(torch.int32)  # [world, nmax] int32 (rows 4-B aligned by construction)
-        if self.equal:  # one strided copy per array
-            self.flags_all.view(W, nm).copy_(recv_info[:, :nm])
-            if self._has_reward:
-                self.reward_all.view(W, nm).copy_(words(self._off_reward))
-            if self._has_steps:
-                self.step_count_all.view(W, nm).copy_(words(self._off_steps))
-        else:
-            for r in range(W):
-                lo, c = self.offsets[r], self.counts[r]
-                self.flags_all[lo:lo + c].copy_(recv_info[r, :c])
-                if self._has_reward:
-                    self.reward_all[lo:lo + c].copy_(words(self._off_reward)[r, :c])
-                if self._has_steps:
-                    self.step_count_all[lo:lo + c].copy_(words(self._off_steps)[r, :c])
-        f = self.flags_all
-        info = {"flags": f, "done": done_from_flags(f), "is_won": (f & _FLAG_IS_WON) != 0, "invalid_move": (f & _FLAG_INVALID_MOVE) != 0,
-                "success": (f & _FLAG_SUCCESS) != 0, "timeout": (f & _FLAG_TIMEOUT) != 0}
-        if self._has_reward:
-            info["reward"] = self.reward_all
-        if self._has_steps:
-            info["step_count"] = self.step_count_all  # AFTER the step's increment (the environment's counter; StepInfo subtracts it back)
-        return info
+    def _unpack_message(self, recv, with_pos):
+        """recv: uint8 [world, message bytes] as received -> pos_flat (compact form), flags_all / reward_all / step_count_all
+        (padding dropped), in one launch; returns the info of the gathered batch."""
+        self._unpack(self, recv, self._info_fields | (HANDOFF_CELLS if with_pos else 0))
+        return HandoffInfo(self.flags_all, self.reward_all, self.step_count_all)
 
-    def _finish(self, work, fn, async_op):
-        def fin():
-            res = fn()
-            self.info = res[1]
-            return res
-        h = GatherHandle(work, fin)
+    def _finish(self, work, receive, finish, async_op, two_phase=False):
+        """receive(): what follows the collective at once (unpack; returns the info); finish(): the rest (returns the observations)."""
+        before = self._pending if self._pending is not None and not self._pending.finished else None  # (received, compact: see _require_idle)
+
+        def rec():
+            if before is not None and not before.finished:
+                raise RuntimeError("wait() on the previous hand-off's handle before receive() / wait() on this one: unpacking this "
+                                   "message overwrites the cell rows the previous ts_encode has yet to read")
+            self.info = receive()
+            return self.info
+        h = GatherHandle(work, rec, finish, two_phase)
         self._pending = h
         return h if async_op else h.wait()
 
-    def _require_idle(self):
-        """Called before a gather touches any buffer: the previous handle must have been waited for."""
-        if self._pending is not None and not self._pending.finished:
+    def _require_idle(self, compact=False):
+        """Called before a gather touches any buffer: the previous handle must have been waited for - or, between two compact
+        hand-offs, at least received (its message is unpacked; its ts_encode may follow the new collective's launch)."""
+        h = self._pending
+        if h is not None and not h.finished and not (compact and h.two_phase and h.received):
             raise RuntimeError("a gather is still in flight on this ObservationGatherer: call wait() on its handle before "
-                               "issuing the next one (the receive buffers are single-buffered)")
+                               "issuing the next one (the receive buffers are single-buffered; between two "
+                               "gather_compact_and_encode calls receive() is enough)")
 
     def _check_async_obs(self, async_op):
         ring = getattr(self.env, "_obs_ring", None)
@@ -342,11 +444,9 @@ class ObservationGatherer:
         w = self._gather(self._padded_obs, self._padded_rows(obs, "obs"), async_op)
         wi, recv_info = self._info_collective(async_op)
 
-        def fin():
-            if not self.receives:
-                return None, None
-            return self._compact(), self._unpack_info(recv_info)
-        return self._finish([w, wi], fin, async_op)
+        rec = lambda: self._unpack_message(recv_info, False) if self.receives else None
+        fin = lambda: self._compact() if self.receives else None
+        return self._finish([w, wi], rec, fin, async_op)
 
     def gather_u8_and_expand(self, obs=None, async_op=False):
         if self._obs_dtype != torch.uint8:
@@ -359,32 +459,29 @@ class ObservationGatherer:
 
         def fin():  # ONE launch over everything received (padding boards included), then drop the padding
             if not self.receives:
-                return None, None
+                return None
             self.expand_fn(self.env, self._recv_u8, self._padded_obs)
-            return self._compact(), self._unpack_info(recv_info)
-        return self._finish([w, wi], fin, async_op)
+            return self._compact()
+        rec = lambda: self._unpack_message(recv_info, False) if self.receives else None
+        return self._finish([w, wi], rec, fin, async_op)
 
     def gather_compact_and_encode(self, async_op=False):
         """ONE collective: cell ids + flags (+ reward, step counters) of the step just taken; the receiving rank(s) re-encode all
         boards with one ts_encode.  The environment needs no observation of its own (obs_dtype=None)."""
         env = self.env
-        self._require_idle()
+        self._require_idle(compact=True)
         # snapshot, stream-ordered behind the step that produced it: the collective (on the backend's stream) reads the
         # slot, never `pos` / `flags` themselves, which the next step rewrites in place
         w = self._gather(self._msg_recv, self._snapshot_message(True), async_op)
 
+        # ts_unpack_handoff: rank-major [world][T][nmax] -> the SoA rows of one batch of world * nmax boards (+ flags ...), then
+        # ONE ts_encode launch over all of them.  The padding boards of a short shard hold zeros, which the kernels accept
+        # like any other cell ids; their rows are dropped by _compact.
+        rec = lambda: self._unpack_message(self._msg_recv, True) if self.receives else None
+
         def fin():
             if not self.receives:
-                return None, None
-            # rank-major [world, T, nmax] -> the SoA rows of one batch of world * nmax boards, then ONE
-            # ts_encode launch over all of them.  The padding boards of a short shard hold zeros, which
-            # the kernels accept like any other cell ids; their rows are dropped by _compact.
-            T = env._pos.shape[0]
-            if T:
-                cells = self._msg_recv[:, :T * self.nmax * self._cell_bytes].view(env._pos.dtype).view(self.world, T, self.nmax)
-                self.pos_flat.view(T, self.world, self.nmax).copy_(cells.permute(1, 0, 2))
-            self.encode_fn(env, SimpleNamespace(n_boards=self.world * self.nmax, pos=self.pos_flat, tgt=self.tgt_flat,
-                                                blk=self.blk_flat, out=self._padded_obs.view((-1,) + tuple(self.obs_all.shape[1:])),
-                                                lines=self.lines_flat))
-            return self._compact(), self._unpack_info(self._msg_recv[:, self._seg_pos:])
-        return self._finish([w], fin, async_op)
+                return None
+            self.encode_fn(env, self._encode_job)
+            return self._compact()
+        return self._finish([w], rec, fin, async_op, two_phase=True)

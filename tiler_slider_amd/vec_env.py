@@ -289,6 +289,7 @@ class VecTilerSliderEnv:
         ring_bytes = (obs_bytes * int(obs_buffers) + (per_board - obs_bytes)) * N
         self._dims.ring_bytes = ring_bytes if int(obs_buffers) > 1 else 0
         self._outputs_beyond_cache = max(per_board * N, self._dims.ring_bytes) > self._PLACEMENT_MIN_BYTES
+        self.output_memory_report = []  # one entry per large output buffer: where it was actually allocated (see _big_zeros)
         self._obs_ring = [self._big_zeros((N, self.size, self.size, 3), obs_dtype) if obs_dtype is not None else None
                           for _ in range(int(obs_buffers))]
         self._obs_slot = 0
@@ -523,6 +524,8 @@ class VecTilerSliderEnv:
         """Output buffers: beyond the Infinity Cache from physically contiguous memory (see `output_memory`)."""
         if not self.host_mapped and self.output_memory == "contiguous" and self._outputs_beyond_cache:
             t = _contiguous_zeros(tuple(shape), dtype, self.device)
+            self.output_memory_report.append({"bytes": int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size(),
+                                              "memory": "contiguous" if t is not None else "torch (contiguous allocation refused)"})
             if t is not None:
                 return t
         return self._zeros(shape, dtype)
