@@ -115,6 +115,15 @@ def test_size_cliffs(shape):
         assert got == want, (shape, limit, delta, got)
 
 
+def test_state_beyond_the_cache():
+    """Batches whose STATE no longer fits the Infinity Cache (profiles/r05_state_spill_probe.log): from ~200 MiB of state four more
+    resident blocks per CU, from ~272 MiB full waves.  4x4 / 2 tiles: 15 bytes of state per board."""
+    got = [(n >> 20, r["boards_per_wave"], r["blocks_per_cu"]) for n in (12 << 20, 14 << 20, 16 << 20, 20 << 20, 64 << 20)
+           for r in [describe(dims(n, 4, 2))]]
+    assert got == [(12, 32, 18), (14, 32, 22), (16, 32, 22), (20, 64, 22), (64, 64, 22)], got
+    assert all(describe(dims(n, 4, 2))["name"] == "k_small<4, 2, false, true>" for n in (12 << 20, 20 << 20))
+
+
 # ---- launches without an image output (round 5) ----------------------------------------------------------------------
 def test_state_only_launches():
     """Above 8x8 a launch with no observation / one-hot output runs one board per lane (k_state), whatever the batch size; the

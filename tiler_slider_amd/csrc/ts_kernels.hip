@@ -2558,7 +2558,14 @@ constexpr uint32_t kCachedEverySmall = 16, kCachedEveryWide = 16, kCachedEveryWi
 // Boards per wave of k_small's register forms beyond the cache (r04_small_boards_per_wave*.log, r04_big_chunk_probe.log: a wave's
 // chunk of observation should be 9 .. 14 KB - 4x4 full waves 95.5 -> 90.5 us per 600 MB, 7x7 / 8x8 quarter waves 0.80 -> 0.96)
 constexpr uint64_t kSmallChunkMax = 14 * KiB, kSmallChunkMaxBeyond1G = 7 * KiB;  // (r04_learner_side_sweep.log: 8M 4x4 boards full waves 284 us, half 250)
-constexpr uint64_t kSmallFullWavesStateBytes = 640 * MiB;  // state beyond the cache too: full waves (4x4 at 64M boards 3.35 -> 2.57 ms)
+// Batches whose STATE (cells, targets, obstacle words, counters: what a step re-reads) no longer fits the 256 MiB Infinity Cache
+// (profiles/r05_state_spill_probe.log, 4x4 / 2 tiles, fraction of 8 TB/s with half waves / full waves): 14M boards (210 MiB of state)
+// 0.825 / 0.707, 16M (240 MiB) 0.706 / 0.655, 20M (300 MiB) 0.589 / 0.751, 24M 0.577 / 0.737 - full waves (wider pieces of every state
+// row) from ~272 MiB on (round 4 had 640 MiB from one 64M-board point); and from ~200 MiB on four more resident blocks per CU
+// (14M 0.825 -> 0.848, 16M 0.706 -> 0.751, 20M with full waves 0.751 -> 0.757; at 12M, 180 MiB, nothing: 0.901 / 0.896)
+constexpr uint64_t kSmallFullWavesStateBytes = 272 * MiB;
+constexpr uint64_t kSmallStateSpillBytes = 200 * MiB;
+constexpr int kSmallStateSpillExtraBlocks = 4;
 constexpr uint64_t kHugeStream = 1200 * MiB;               // 7x7 / 8x8 beyond it: half waves + eighths (r04_large_batch_probe.log: 0.62 -> 0.88)
 constexpr uint64_t kHugeStreamMinPrimary = 12 * 49;        //   ... "7x7 / 8x8" = from 588 B of observation per board on
 constexpr uint64_t kBeyond1G = 1024 * MiB;                 // up to 6x6 with >= 20 B of state per board: full waves beyond it
@@ -2681,9 +2688,9 @@ int small_boards_per_wave(bool out_of_cache, bool register_path, uint64_t primar
 #else
   if (!out_of_cache || !register_path || TS_OOC_WAVES == 0) return kWave;  // (the any-tile-count path is bound by its serial tile
                                                                              // loops: half waves 101.8 -> 120.9 us at 6x6 / 12 tiles)
-  // Once the STATE of the batch no longer fits the Infinity Cache either (tens of millions of boards) a partial wave's short
-  // pieces of every state row cost more than its shorter chunk wins: 4x4 at 64M boards 3.35 ms with half waves, 2.57 with full
-  // ones (at 16M boards, 300 MB of state, half waves still win: 592 vs 722 us).
+  // Once the STATE of the batch no longer fits the Infinity Cache either a partial wave's short pieces of every state row cost
+  // more than its shorter chunk wins (policy::kSmallFullWavesStateBytes: 4x4 at 20M boards 0.589 -> 0.751 of the roofline; at 16M
+  // boards half waves still win).
   if (state_bytes > policy::kSmallFullWavesStateBytes) return kWave;
   if (const int64_t forced = g_small_bpw.load(std::memory_order_relaxed); forced == 16 || forced == 32 || forced == 64) return (int)forced;
   // (Streams beyond 1 GiB - cfg3's learner re-encoding 8,388,608 gathered 4x4 boards: 1.6 GB - want the shorter chunk again:
@@ -2857,6 +2864,8 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     a.bpw = (uint32_t)small_boards_per_wave(a.nt != 0, tfix > 0, a.obs ? 12ull * C : a.obs_u8 ? 3ull * C : 4ull * C * a.onehot_ch,
                                             (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7), (uint64_t)d->n_boards);
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
+    if (res.blocks_per_cu > 0 && (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7) > policy::kSmallStateSpillBytes)
+      res.blocks_per_cu += policy::kSmallStateSpillExtraBlocks;  // the state comes from HBM too: more waves in flight to wait for it
     if (a.emit_edges == 0xffu) {
       const uint64_t chunk = (uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch);
       const uint64_t sites = ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw * ((a.obs && a.onehot) ? 2u : 1u);
