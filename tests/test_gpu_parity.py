@@ -329,6 +329,29 @@ def test_full_size_oracle_replay_and_properties(torch_cuda, oracle, S, T, K, N, 
     assert bool((obs[..., 1].sum(dim=(1, 2)) == T * (T + 1) // 2).all())
 
 
+def test_state_beyond_the_infinity_cache_vs_oracle(torch_cuda, oracle):
+    """20M 4x4 boards: 4.4 GB of observation per launch and 300 MiB of state, where the launch policy switches to full waves with
+    four more resident blocks per CU (profiles/r05_state_spill_probe.log) - a complete oracle replay of a reset and three steps."""
+    torch = torch_cuda
+    from tiler_slider_amd import VecTilerSliderEnv, _cabi
+    N = 20 * (1 << 20) + 3
+    env = VecTilerSliderEnv.random(N, size=4, num_tiles=2, num_obstacles=2, seed=0xB16B0A2D, multi_color=True, max_steps=2, auto_reset=True,
+                                   obs_candidates=0)
+    d = _cabi.describe_launch(env._dims, _cabi.OP_STEP, _cabi.OUT_OBS | _cabi.OUT_FLAGS)
+    assert (d["name"], d["boards_per_wave"], d["blocks_per_cu"]) == ("k_small<4, 2, false, true>", 64, 22)
+    ref = oracle.OracleBatch(4, True, 2, env._blk.cpu().numpy().view(np.uint32), env._init.cpu().numpy(), env._tgt.cpu().numpy())
+    assert np.array_equal(env.reset().cpu().numpy(), ref.reset())
+    for step in range(3):  # episodes of two steps: the third step resets every board in place
+        act = oracle.fill_actions(N, seed=0xAC710005, step_index=step)
+        obs, done, info = env.step(torch.from_numpy(act))
+        want = ref.step(act, mode=oracle.MODE_AUTORESET)
+        assert np.array_equal(info["flags"].cpu().numpy(), want["flags"]), step
+        assert np.array_equal(env.positions.cpu().numpy(), ref.pos), step
+        assert np.array_equal(obs.cpu().numpy(), want["obs"]), step
+        del want, obs
+    assert bool(((info["flags"] & _cabi.FLAG_AUTORESET) != 0).all())
+
+
 def test_strict_mode_raises_like_reference(torch_cuda):
     torch = torch_cuda
     from tiler_slider_amd import Move, VecTilerSliderEnv
