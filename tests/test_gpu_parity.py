@@ -110,7 +110,7 @@ RANDOM_SHAPES = [
     (5, 2, 3, True, 4099, 12), (5, 2, 3, False, 2049, 12), (5, 7, 5, False, 1500, 40), (6, 1, 6, True, 999, 10),
     (6, 9, 6, True, 640, 40), (7, 2, 9, False, 1111, 10), (7, 12, 9, True, 321, 40), (8, 2, 12, True, 2050, 10),
     (8, 30, 10, False, 259, 40), (8, 60, 2, True, 131, 40),
-    (9, 4, 9, True, 1023, 12), (10, 20, 0, False, 515, 40), (12, 16, 20, True, 258, 40), (13, 1, 30, False, 130, 9),
+    (9, 4, 9, True, 1023, 12), (10, 3, 7, True, 1021, 12), (10, 20, 0, False, 515, 40), (12, 16, 20, True, 258, 40), (13, 1, 30, False, 130, 9),
     (15, 32, 24, True, 1030, 40), (15, 32, 24, False, 259, 40), (16, 40, 30, True, 66, 40), (16, 255, 0, False, 9, 40),
     # above 16x16: uint16 cell ids, 32-bit line masks
     (17, 3, 20, True, 257, 12), (20, 1, 1, False, 130, 9), (24, 30, 60, True, 67, 40), (27, 100, 90, False, 18, 40),

@@ -65,7 +65,7 @@ def test_bench_extra_shapes():
     """bench.py --config ...: the 3.4 x Infinity-Cache sibling of cfg1 and the shapes of tools/soak.py."""
     assert row(dims(1 << 22, 4, 2)) == ("k_small<4, 2, false, true>", 1, 64, 0, 3, 32, 1, 18, 65536)
     assert row(dims(1 << 19, 8, 20)) == ("k_deal<8, 4, 5, false, true>", 1, 16, 0, 3, 16, 4, 0, 8192)   # not k_small: tiles dealt over 4 lanes
-    assert row(dims(1 << 19, 9, 4)) == ("k_lines<false, 4, 1, true, false>", 1, 16, 0, 3, 16, 1, 10, 32768)
+    assert row(dims(1 << 19, 9, 4)) == ("k_lines<false, 4, 1, true, false>", 1, 12, 0, 3, 16, 1, 18, 43691)   # twelve boards per wave: the chunk rule
     assert row(dims(1 << 18, 12, 8)) == ("k_lines<false, 8, 1, true, false>", 1, 8, 0, 3, 16, 1, 14, 32768)
     assert row(dims(1 << 15, 32, 64)) == ("k_lines<true, 32, 2, true, false>", 1, 2, 16, 3, 16, 1, 9, 16384)
     assert row(dims(1 << 20, 7, 5)) == ("k_small<7, 5, false, true>", 1, 16, 16, 3, 32, 1, 16, 65536)
@@ -113,6 +113,16 @@ def test_size_cliffs(shape):
     for (limit, delta), want in sorted(CLIFFS[shape].items()):
         got = row(dims(_boards(S, limit, delta), S, T))[:-1]
         assert got == want, (shape, limit, delta, got)
+
+
+def test_four_lane_boards_follow_the_chunk_rule():
+    """k_lines with four lanes per board beyond the cache: the largest of 16 / 12 / 8 boards per wave whose float32 chunk stays
+    within 14 KB (profiles/r05_lines_bpw_probe.log); cache-resident launches and uint8 observations keep sixteen."""
+    n9, n10 = (600 << 20) // (12 * 81), (600 << 20) // (12 * 100)
+    assert [(r["name"], r["boards_per_wave"], r["blocks_per_cu"]) for r in (describe(dims(n9, 9, 4)), describe(dims(n10, 10, 3)))] == \
+        [("k_lines<false, 4, 1, true, false>", 12, 18), ("k_lines<false, 4, 1, true, false>", 8, 22)]
+    assert describe(dims(1 << 16, 9, 4))["boards_per_wave"] == 16
+    assert describe(dims(n9 * 4, 9, 4), STEP, _cabi.OUT_OBS_U8 | FLAGS)["boards_per_wave"] == 16
 
 
 def test_state_beyond_the_cache():

@@ -2956,6 +2956,15 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     // 92.2 -> 79.9 us, 32x32 / 4 tiles 91.1 -> 81.3; with 32 tiles the slide's idle lanes cost what the shorter chunk wins
     // (87.8 -> 91.4: stays at two).  profiles/r04_lines_bpw_sweep_32lanes.log
     if (a.nt && lpb == 32 && S >= policy::kLinesOneBoardMinS && maxT <= policy::kLinesOneBoardMaxT) a.bpw = 1;  // (S is even here: 12 * C is a multiple of 16)
+    // Four lanes per board (9x9 / 10x10 with at most four tiles): sixteen boards are a chunk of 15.6 / 19.2 KB - the chunk rule of the
+    // other kernels (9 .. 14 KB per wave) gives twelve boards at 9x9 and eight at 10x10: 9x9 / 4 tiles at 528 MB 79.7 -> 77.0 us,
+    // one tile 77.4 -> 74.2; 10x10 with four lanes 89.3 -> 81.3 (profiles/r05_lines_bpw_probe.log)
+    if (a.nt && a.obs && lpb == 4)
+      for (const int b : {16, 12, 8})
+        if (12ull * C * b <= policy::kSmallChunkMax && (3 * C * b) % 4 == 0) {
+          a.bpw = (uint32_t)b;
+          break;
+        }
     // (a wave's chunk of float32 output must start on a 16-byte boundary: 12 * C * bpw % 16 == 0)
     if (const int64_t forced = g_lines_bpw.load(std::memory_order_relaxed); forced >= 1 && forced <= bpw_max && (3 * C * forced) % 4 == 0) a.bpw = (uint32_t)forced;
     Residency res = ooc_residency(a.nt != 0, true, false,
