@@ -53,8 +53,8 @@ def test_baseline_configs():
                     "resident_bytes": 838860800, "name": "k_small<5, 2, true, true>"}
     cfg4 = describe(dims(1 << 18, 15, 32))
     assert cfg4 == {"kernel": 4, "out_of_cache": 1, "lanes_per_board": 16, "boards_per_lane": 1, "boards_per_wave": 4, "tiles_per_lane": 2,
-                    "extras": 0, "wide": 0, "cached_every": 0, "emit_edges": 3, "xcd_piece": 16, "waves_per_block": 1, "blocks_per_cu": 18,
-                    "lds_bytes_block": 8624, "lds_bytes_used": 3472, "blocks": 65536, "output_bytes": 707788800,
+                    "extras": 0, "wide": 0, "cached_every": 0, "emit_edges": 3, "xcd_piece": 24, "waves_per_block": 4, "blocks_per_cu": 7,
+                    "lds_bytes_block": 20496, "lds_bytes_used": 13888, "blocks": 16384, "output_bytes": 707788800,  # four-wave blocks (round 5)
                     "resident_bytes": 707788800, "name": "k_lines<false, 16, 2, true, false>"}
     # cfg3 = cfg1 per GPU; the learner's re-encode of all 8 x 1,048,576 gathered boards (1.6 GB: half waves again)
     learner = row(dims(8 << 20, 4, 2), OBSERVE, OBS)
@@ -97,9 +97,10 @@ CLIFFS = {
              (704, -1): ("k_small<8, 4, false, true>", 1, 16, 16, 3, 32, 1, 18), (704, 1): ("k_small<8, 4, false, true>", 1, 16, 0, 3, 32, 1, 18),
              (1024, -1): ("k_small<8, 4, false, true>", 1, 16, 0, 1, 32, 1, 18), (1024, 1): ("k_small<8, 4, false, true>", 1, 64, 0, 3, 32, 1, 8),
              (1200, -1): ("k_small<8, 4, false, true>", 1, 64, 0, 3, 32, 1, 8), (1200, 1): ("k_small<8, 4, false, true>", 1, 32, 0, 3, 0, 1, 8)},
-    (15, 32): {(256, -1): ("k_lines<false, 16, 2, false, false>", 0, 4, 0, 0, -1, 4, 0), (256, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 3, 16, 1, 18),
-               (704, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 3, 16, 1, 18), (1024, -1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 2, 16, 1, 18),
-               (1200, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 0, 16, 1, 18)},  # (a single edge beyond 1 GiB: up to 112 MiB of it)
+    # 16 lanes per board beyond the cache: four-wave blocks, ceil(18 / 4) resident blocks per CU + 2 up to 1 GiB, pieces of 24 blocks
+    (15, 32): {(256, -1): ("k_lines<false, 16, 2, false, false>", 0, 4, 0, 0, -1, 4, 0), (256, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 3, 24, 4, 7),
+               (704, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 3, 24, 4, 7), (1024, -1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 2, 24, 4, 7),
+               (1200, 1): ("k_lines<false, 16, 2, true, false>", 1, 4, 0, 0, 24, 4, 5)},  # (a single edge beyond 1 GiB: up to 112 MiB of it)
     (20, 6): {(256, -1): ("k_lines<true, 32, 1, false, false>", 0, 2, 0, 0, -1, 4, 0), (256, 1): ("k_lines<true, 32, 1, true, false>", 1, 2, 16, 3, 16, 1, 22),
               (512, -1): ("k_lines<true, 32, 1, true, false>", 1, 2, 16, 3, 16, 1, 22), (512, 1): ("k_lines<true, 32, 1, true, false>", 1, 2, 32, 3, 16, 1, 22),
               (704, -1): ("k_lines<true, 32, 1, true, false>", 1, 2, 32, 3, 16, 1, 22), (704, 1): ("k_lines<true, 32, 1, true, false>", 1, 2, 0, 3, 16, 1, 22),
@@ -115,6 +116,24 @@ def test_size_cliffs(shape):
         assert got == want, (shape, limit, delta, got)
 
 
+def test_sixteen_lane_boards_run_four_wave_blocks():
+    """k_lines beyond the cache: four waves per block with 16 lanes per board (profiles/r05_lines_waves_per_block_probe.log); one-wave
+    blocks with 8 and 32 lanes, for two-stream launches, and when ts_tuning(TS_TUNE_LINES_WAVES) says so."""
+    n = lambda S: (600 << 20) // (12 * S * S)
+    got = {(S, T): (r["lanes_per_board"], r["waves_per_block"], r["blocks_per_cu"], r["xcd_piece"]) for S, T in ((14, 20), (16, 16), (15, 8), (12, 8), (24, 30))
+           for r in [describe(dims(n(S), S, T))]}
+    assert got == {(14, 20): (16, 4, 8, 24), (16, 16): (16, 4, 4, 24), (15, 8): (16, 4, 5, 24), (12, 8): (8, 1, 14, 16), (24, 30): (32, 1, 14, 16)}, got
+    assert describe(dims(n(15), 15, 32), outs=OBS | RW | VALID)["waves_per_block"] == 4
+    assert describe(dims(n(15) // 4, 15, 32), outs=OBS | OH)["waves_per_block"] == 1
+    L = _cabi.lib()
+    before = L.ts_tuning(_cabi.TUNE_LINES_WAVES, 1)
+    try:
+        r = describe(dims(1 << 18, 15, 32))
+        assert (r["waves_per_block"], r["blocks_per_cu"], r["xcd_piece"], r["blocks"]) == (1, 18, 16, 65536)
+    finally:
+        L.ts_tuning(_cabi.TUNE_LINES_WAVES, before)
+
+
 def test_four_lane_boards_follow_the_chunk_rule():
     """k_lines with four lanes per board beyond the cache: the largest of 16 / 12 / 8 boards per wave whose float32 chunk stays
     within 14 KB (profiles/r05_lines_bpw_probe.log); cache-resident launches and uint8 observations keep sixteen."""
@@ -122,6 +141,7 @@ def test_four_lane_boards_follow_the_chunk_rule():
     assert [(r["name"], r["boards_per_wave"], r["blocks_per_cu"]) for r in (describe(dims(n9, 9, 4)), describe(dims(n10, 10, 3)))] == \
         [("k_lines<false, 4, 1, true, false>", 12, 18), ("k_lines<false, 4, 1, true, false>", 8, 22)]
     assert describe(dims(1 << 16, 9, 4))["boards_per_wave"] == 16
+    assert describe(dims((700 << 20) // (12 * 81), 9, 4))["boards_per_wave"] == 16  # the rule ends at 640 MiB per launch
     assert describe(dims(n9 * 4, 9, 4), STEP, _cabi.OUT_OBS_U8 | FLAGS)["boards_per_wave"] == 16
 
 

@@ -2341,6 +2341,7 @@ std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): I
 std::atomic<int64_t> g_mt_window{kMtLongWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
 std::atomic<int64_t> g_cached_every{0};  // ts_tuning(TS_TUNE_CACHED_EVERY): 0 = policy, 1 = never, N >= 2 = every N-th wave of every k_small launch beyond the cache
 std::atomic<int64_t> g_small_bpw{0};  // ts_tuning(TS_TUNE_SMALL_BPW): 0 = policy, 16 / 32 / 64 = boards per wave of k_small's register forms beyond the cache
+std::atomic<int64_t> g_lines_waves{0};  // ts_tuning(TS_TUNE_LINES_WAVES): 0 = policy, 1 / 2 / 4 = waves per block of k_lines beyond the Infinity Cache
 std::atomic<int64_t> g_state_only{1};    // ts_tuning(TS_TUNE_STATE_ONLY): 0 = launches without an image output stay on k_lines above 8x8
 std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
 std::atomic<int64_t> g_emit_edges{4};   // ts_tuning(TS_TUNE_EMIT_EDGES): 0 .. 3 forced, 4 = policy
@@ -2579,6 +2580,18 @@ constexpr int lookup(const ByChunk *rows, uint64_t chunk) {
   while (chunk < rows->min_chunk) ++rows;
   return rows->value;
 }
+// k_lines beyond the cache: one-wave blocks - except the 16-lane form (four boards per wave: 14x14 .. 16x16, and smaller boards with
+// many tiles), whose waves touch T + Tt narrow state rows for 4 bytes each.  There a block has FOUR waves, which share the CU's L1
+// for those lines (sixteen boards' bytes of every row per block), ceil(b / 4) resident blocks per CU where one-wave blocks have b,
+// two more for boards with 40 and more state rows in launches up to 1 GiB, pieces of 24 blocks per XCD
+// (profiles/r05_lines_waves_per_block_probe.log, best one-wave cell -> best four-wave cell, us): cfg4 107.9 -> 102.8 (0.862 -> 0.905),
+// 15x15 / 24 tiles 74.4 -> 69.0, 14x14 / 20 tiles 74.9 -> 70.1, 16x16 / 40 tiles 88.2 -> 75.1, 16x16 / 16 tiles 66.6 -> 63.9, 15x15 / 8
+// tiles 93.9 -> 91.8; cfg4's shape at 1.5 GB 222 (policy) -> 212.  The forms with 8 lanes gain nothing (12x12 73.5 -> 73.0), those
+// with 32 lanes go either way (24x24 70.8 -> 67.9, 32x32 68.3 -> 72.0): both stay with one-wave blocks.
+constexpr uint64_t kLinesChunkRuleMaxBytes = 640 * MiB;  // four lanes per board: the 14 KB chunk rule up to this many bytes per launch
+constexpr int kLinesDenseLanes = 16, kLinesDenseWaves = 4, kLinesDenseRows = 40, kLinesDenseExtraBlocks = 2;
+constexpr uint64_t kLinesDenseExtraMaxBytes = 1024 * MiB;
+constexpr uint32_t kPieceDenseBlocks = 24;
 // k_state: eight cells (and targets) in flight per lane up to this many tiles, sixteen above (r05_state_only_ab.log)
 constexpr int kStateBatch8MaxT = 8;
 }  // namespace policy
@@ -2602,6 +2615,12 @@ Residency ooc_residency(bool out_of_cache, bool lines_kernel, bool compute_heavy
   int blocks = policy::lookup(policy::kSmallBlocksPerCu, chunk);
   if (chunk >= policy::kSmallMidChunk && chunk < 11u * policy::KiB && tiles > policy::kSmallMidChunkTiles) blocks = policy::kSmallMidChunkBlocksManyTiles;
   return {1, blocks};
+}
+
+// Waves per block of k_lines beyond the Infinity Cache (policy::kLinesDense*; ts_tuning(TS_TUNE_LINES_WAVES) forces 1 / 2 / 4).
+int lines_waves_policy(int lanes_per_board, bool single_f32_stream) {
+  if (const int64_t forced = g_lines_waves.load(std::memory_order_relaxed); forced == 1 || forced == 2 || forced == 4) return (int)forced;
+  return (single_f32_stream && lanes_per_board == policy::kLinesDenseLanes) ? policy::kLinesDenseWaves : 1;
 }
 
 // Which store instructions of a wave's chunk go out as write-back stores instead of nontemporal ones (KArgs.emit_edges):
@@ -2959,7 +2978,9 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     // Four lanes per board (9x9 / 10x10 with at most four tiles): sixteen boards are a chunk of 15.6 / 19.2 KB - the chunk rule of the
     // other kernels (9 .. 14 KB per wave) gives twelve boards at 9x9 and eight at 10x10: 9x9 / 4 tiles at 528 MB 79.7 -> 77.0 us,
     // one tile 77.4 -> 74.2; 10x10 with four lanes 89.3 -> 81.3 (profiles/r05_lines_bpw_probe.log)
-    if (a.nt && a.obs && lpb == 4)
+    // - up to 640 MiB per launch: at 2.1 GB, where the state of 9x9 boards no longer fits the cache, twelve boards cost 15 % against
+    // sixteen (475 against 404 - 416 us: fewer, wider state reads win there)
+    if (a.nt && a.obs && lpb == 4 && 12ull * C * (uint64_t)d->n_boards <= policy::kLinesChunkRuleMaxBytes)
       for (const int b : {16, 12, 8})
         if (12ull * C * b <= policy::kSmallChunkMax && (3 * C * b) % 4 == 0) {
           a.bpw = (uint32_t)b;
@@ -2969,11 +2990,21 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     if (const int64_t forced = g_lines_bpw.load(std::memory_order_relaxed); forced >= 1 && forced <= bpw_max && (3 * C * forced) % 4 == 0) a.bpw = (uint32_t)forced;
     Residency res = ooc_residency(a.nt != 0, true, false,
                                         (uint64_t)a.bpw * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)), T);
+    bool dense_blocks = false;  // several waves per block beyond the cache (lines_waves_policy)
+    if (res.blocks_per_cu > 0) {
+      const int w = lines_waves_policy(lpb, a.obs != nullptr && a.onehot == nullptr);
+      if (w > 1) {
+        res.waves_per_block = w;
+        res.blocks_per_cu = (res.blocks_per_cu + w - 1) / w;
+        if (T + Tt >= policy::kLinesDenseRows && 12ull * C * (uint64_t)d->n_boards <= policy::kLinesDenseExtraMaxBytes) res.blocks_per_cu += policy::kLinesDenseExtraBlocks;
+        dense_blocks = true;
+      }
+    }
     apply_launch_hint(res, d->launch_hint);
     if (a.emit_edges == 0xffu)
       a.emit_edges = edge_policy_capped((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch),
                                             ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw + (a.onehot ? (uint64_t)d->n_boards * C * a.onehot_ch / 8192u : 0u), false);
-    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
+    if (a.xcd_piece == 0xffffffffu) a.xcd_piece = dense_blocks ? policy::kPieceDenseBlocks : piece_policy(true, 0);
     a.cached_every = a.nt ? cached_every_policy(S, (uint64_t)d->n_boards * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)),
                                                         a.onehot != nullptr) : 0u;
     int waves = (res.waves_per_block > 0 && res.waves_per_block <= TS_LINES_WAVES) ? res.waves_per_block : TS_LINES_WAVES;
@@ -3351,7 +3382,8 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_MT_WINDOW ? &g_mt_window
                                : key == TS_TUNE_SMALL_BPW ? &g_small_bpw
                                : key == TS_TUNE_CACHED_EVERY ? &g_cached_every
-                               : key == TS_TUNE_STATE_ONLY ? &g_state_only : nullptr;
+                               : key == TS_TUNE_STATE_ONLY ? &g_state_only
+                               : key == TS_TUNE_LINES_WAVES ? &g_lines_waves : nullptr;
   if (!knob) return -1;
   if (key == TS_TUNE_MT_WINDOW && value > kMtLongWindow) value = kMtLongWindow;  // output 623 wraps around to twisted word 0
   return value >= 0 ? knob->exchange(value) : knob->load();
