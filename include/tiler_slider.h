@@ -374,6 +374,9 @@ int32_t ts_describe_launch(const ts_dims *dims, uint32_t op, uint32_t outputs_ma
 #define TS_TUNE_STATE_ONLY 10 /* 1 (default): above 8x8, launches with no image output (ts_is_won, ts_valid_moves(4), multi-colour
                                * ts_reward, ts_step / ts_reset without an observation) run one board per lane (k_state); 0: they stay
                                * on the image kernel (k_lines) - kept for A/B and as the parity cross-check */
+#define TS_TUNE_SMALL_WAVES 12 /* waves per block of the one-lane-per-board kernel beyond the Infinity Cache: 0 (default) = the policy (four
+                               * waves for boards up to 5x5 with one float32 stream of up to 1 GiB: 4x4 at 4M boards 122.0 -> 117.0 us;
+                               * else one); 1 / 2 / 4 = forced, resident blocks per CU scaled accordingly */
 #define TS_TUNE_LINES_WAVES 11 /* waves per block of k_lines beyond the Infinity Cache: 0 (default) = the policy (one-wave blocks; four waves
                                * with 16 lanes per board - the waves of a block share the CU's L1 for the narrow state rows: cfg4
                                * 107.9 -> 102.8 us); 1 / 2 / 4 = forced (resident blocks per CU scaled accordingly) */

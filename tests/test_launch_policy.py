@@ -63,7 +63,7 @@ def test_baseline_configs():
 
 def test_bench_extra_shapes():
     """bench.py --config ...: the 3.4 x Infinity-Cache sibling of cfg1 and the shapes of tools/soak.py."""
-    assert row(dims(1 << 22, 4, 2)) == ("k_small<4, 2, false, true>", 1, 64, 0, 3, 32, 1, 18, 65536)
+    assert row(dims(1 << 22, 4, 2)) == ("k_small<4, 2, false, true>", 1, 64, 0, 3, 64, 4, 7, 16384)   # four-wave blocks up to 5x5 and 1 GiB
     assert row(dims(1 << 19, 8, 20)) == ("k_deal<8, 4, 5, false, true>", 1, 16, 0, 3, 16, 4, 0, 8192)   # not k_small: tiles dealt over 4 lanes
     assert row(dims(1 << 19, 9, 4)) == ("k_lines<false, 4, 1, true, false>", 1, 12, 0, 3, 16, 1, 18, 43691)   # twelve boards per wave: the chunk rule
     assert row(dims(1 << 18, 12, 8)) == ("k_lines<false, 8, 1, true, false>", 1, 8, 0, 3, 16, 1, 14, 32768)
@@ -79,15 +79,16 @@ def _boards(S, limit_mib, delta):
     return n - n % 2
 
 
+# (boards up to 5x5 between 256 MiB and 1 GiB: four-wave blocks, ceil(b / 4) + 2 resident blocks per CU, pieces of 64 - round 5)
 CLIFFS = {
     # (S, T): {(limit MiB, -1 / +1): (name, out_of_cache, boards per wave, cached_every, emit_edges, xcd_piece, waves per block, blocks per CU)}
-    (4, 2): {(256, -1): ("k_multi<4, 2, false, 2>", 0, 128, 0, 0, -1, 4, 0), (256, 1): ("k_small<4, 2, false, true>", 1, 64, 16, 3, 32, 1, 18),
-             (704, -1): ("k_small<4, 2, false, true>", 1, 64, 16, 3, 32, 1, 18), (704, 1): ("k_small<4, 2, false, true>", 1, 64, 0, 3, 32, 1, 18),
-             (1024, -1): ("k_small<4, 2, false, true>", 1, 64, 0, 3, 32, 1, 18), (1024, 1): ("k_small<4, 2, false, true>", 1, 32, 0, 0, 64, 1, 18),
+    (4, 2): {(256, -1): ("k_multi<4, 2, false, 2>", 0, 128, 0, 0, -1, 4, 0), (256, 1): ("k_small<4, 2, false, true>", 1, 64, 16, 3, 64, 4, 7),
+             (704, -1): ("k_small<4, 2, false, true>", 1, 64, 16, 3, 64, 4, 7), (704, 1): ("k_small<4, 2, false, true>", 1, 64, 0, 3, 64, 4, 7),
+             (1024, -1): ("k_small<4, 2, false, true>", 1, 64, 0, 3, 64, 4, 7), (1024, 1): ("k_small<4, 2, false, true>", 1, 32, 0, 0, 64, 1, 18),
              (1200, -1): ("k_small<4, 2, false, true>", 1, 32, 0, 0, 64, 1, 18), (1200, 1): ("k_small<4, 2, false, true>", 1, 32, 0, 0, 64, 1, 18)},
-    (5, 6): {(256, -1): ("k_small<5, 6, false, false>", 0, 64, 0, 0, -1, 4, 0), (256, 1): ("k_small<5, 6, false, true>", 1, 32, 16, 3, 32, 1, 16),
-             (704, -1): ("k_small<5, 6, false, true>", 1, 32, 16, 3, 32, 1, 16), (704, 1): ("k_small<5, 6, false, true>", 1, 32, 0, 3, 32, 1, 16),
-             (1024, -1): ("k_small<5, 6, false, true>", 1, 32, 0, 1, 32, 1, 16), (1024, 1): ("k_small<5, 6, false, true>", 1, 64, 0, 3, 32, 1, 14),
+    (5, 6): {(256, -1): ("k_small<5, 6, false, false>", 0, 64, 0, 0, -1, 4, 0), (256, 1): ("k_small<5, 6, false, true>", 1, 32, 16, 3, 64, 4, 6),
+             (704, -1): ("k_small<5, 6, false, true>", 1, 32, 16, 3, 64, 4, 6), (704, 1): ("k_small<5, 6, false, true>", 1, 32, 0, 3, 64, 4, 6),
+             (1024, -1): ("k_small<5, 6, false, true>", 1, 32, 0, 1, 64, 4, 6), (1024, 1): ("k_small<5, 6, false, true>", 1, 64, 0, 3, 32, 1, 14),
              (1200, -1): ("k_small<5, 6, false, true>", 1, 64, 0, 3, 32, 1, 14), (1200, 1): ("k_small<5, 6, false, true>", 1, 64, 0, 1, 0, 1, 14)},
     (6, 3): {(256, -1): ("k_small<6, 3, false, false>", 0, 64, 0, 0, -1, 4, 0), (256, 1): ("k_small<6, 3, false, true>", 1, 32, 16, 3, 32, 1, 18),
              (704, -1): ("k_small<6, 3, false, true>", 1, 32, 16, 3, 32, 1, 18), (704, 1): ("k_small<6, 3, false, true>", 1, 32, 0, 3, 32, 1, 18),
@@ -132,6 +133,23 @@ def test_sixteen_lane_boards_run_four_wave_blocks():
         assert (r["waves_per_block"], r["blocks_per_cu"], r["xcd_piece"], r["blocks"]) == (1, 18, 16, 65536)
     finally:
         L.ts_tuning(_cabi.TUNE_LINES_WAVES, before)
+
+
+def test_small_boards_run_four_wave_blocks_up_to_one_gib():
+    """k_small beyond the cache: four waves per block for boards up to 5x5 with one float32 stream of up to 1 GiB
+    (profiles/r05_small_waves_probe.log); not for 6x6 and larger, not for cfg2's two streams, not beyond 1 GiB."""
+    n = lambda S, mb=600: (mb << 20) // (12 * S * S)
+    got = {S: (r["waves_per_block"], r["blocks_per_cu"], r["xcd_piece"]) for S, T in ((3, 1), (4, 2), (5, 2), (6, 3), (8, 4)) for r in [describe(dims(n(S), S, T))]}
+    assert got == {3: (4, 7, 64), 4: (4, 7, 64), 5: (4, 6, 64), 6: (1, 18, 32), 8: (1, 18, 32)}, got
+    assert describe(dims(1 << 20, 5, 2), outs=OBS | OH | RW)["waves_per_block"] == 1
+    assert describe(dims(n(4, 1100), 4, 2))["waves_per_block"] == 1
+    L = _cabi.lib()
+    before = L.ts_tuning(_cabi.TUNE_SMALL_WAVES, 1)
+    try:
+        r = describe(dims(1 << 22, 4, 2))
+        assert (r["waves_per_block"], r["blocks_per_cu"], r["xcd_piece"], r["blocks"]) == (1, 18, 32, 65536)
+    finally:
+        L.ts_tuning(_cabi.TUNE_SMALL_WAVES, before)
 
 
 def test_four_lane_boards_follow_the_chunk_rule():

@@ -21,7 +21,7 @@ FLAG_IS_WON, FLAG_INVALID_MOVE, FLAG_SUCCESS, FLAG_TIMEOUT = 0x01, 0x02, 0x04, 0
 FLAG_STEPPED_DONE, FLAG_AUTORESET, FLAG_BAD_ACTION = 0x10, 0x20, 0x40
 MODE_STRICT, MODE_AUTORESET = 0, 1
 TUNE_MULTI_MIN_BOARDS, TUNE_NT_THRESHOLD_BYTES, TUNE_LINES_LANES, TUNE_LINES_BPW, TUNE_EMIT_EDGES, TUNE_XCD_PIECE = 0, 1, 2, 3, 4, 5
-TUNE_DEAL, TUNE_MT_WINDOW, TUNE_SMALL_BPW, TUNE_CACHED_EVERY, TUNE_STATE_ONLY, TUNE_LINES_WAVES = 6, 7, 8, 9, 10, 11
+TUNE_DEAL, TUNE_MT_WINDOW, TUNE_SMALL_BPW, TUNE_CACHED_EVERY, TUNE_STATE_ONLY, TUNE_LINES_WAVES, TUNE_SMALL_WAVES = 6, 7, 8, 9, 10, 11, 12
 
 EXPORTS = ("ts_abi_version", "ts_limits", "ts_status_string", "ts_last_hip_error", "ts_blk_words", "ts_cell_bytes",
            "ts_onehot_channels", "ts_check_dims", "ts_reset", "ts_step", "ts_valid_moves", "ts_is_won", "ts_encode",

@@ -2341,6 +2341,7 @@ std::atomic<int64_t> g_xcd_piece{INT64_MAX};  // ts_tuning(TS_TUNE_XCD_PIECE): I
 std::atomic<int64_t> g_mt_window{kMtLongWindow};  // ts_tuning(TS_TUNE_MT_WINDOW): outputs the streamed form of ts_generate_mt19937 may draw (tests shrink it)
 std::atomic<int64_t> g_cached_every{0};  // ts_tuning(TS_TUNE_CACHED_EVERY): 0 = policy, 1 = never, N >= 2 = every N-th wave of every k_small launch beyond the cache
 std::atomic<int64_t> g_small_bpw{0};  // ts_tuning(TS_TUNE_SMALL_BPW): 0 = policy, 16 / 32 / 64 = boards per wave of k_small's register forms beyond the cache
+std::atomic<int64_t> g_small_waves{0};  // ts_tuning(TS_TUNE_SMALL_WAVES): 0 = policy, 1 / 2 / 4 = waves per block of k_small beyond the cache
 std::atomic<int64_t> g_lines_waves{0};  // ts_tuning(TS_TUNE_LINES_WAVES): 0 = policy, 1 / 2 / 4 = waves per block of k_lines beyond the Infinity Cache
 std::atomic<int64_t> g_state_only{1};    // ts_tuning(TS_TUNE_STATE_ONLY): 0 = launches without an image output stay on k_lines above 8x8
 std::atomic<int64_t> g_deal_enabled{1};  // ts_tuning(TS_TUNE_DEAL): 0 = boards up to 8x8 with more than 8 tiles stay on k_small's one-lane path
@@ -2588,6 +2589,13 @@ constexpr int lookup(const ByChunk *rows, uint64_t chunk) {
 // 15x15 / 24 tiles 74.4 -> 69.0, 14x14 / 20 tiles 74.9 -> 70.1, 16x16 / 40 tiles 88.2 -> 75.1, 16x16 / 16 tiles 66.6 -> 63.9, 15x15 / 8
 // tiles 93.9 -> 91.8; cfg4's shape at 1.5 GB 222 (policy) -> 212.  The forms with 8 lanes gain nothing (12x12 73.5 -> 73.0), those
 // with 32 lanes go either way (24x24 70.8 -> 67.9, 32x32 68.3 -> 72.0): both stay with one-wave blocks.
+// k_small beyond the cache: four-wave blocks for boards up to 5x5 (register forms, one float32 stream up to 1 GiB), ceil(b / 4) + 2
+// resident blocks per CU, pieces of 64 blocks per XCD (profiles/r05_small_waves_probe.log, policy -> best four-wave cell, us): 4x4 at
+// 4M boards 122.0 -> 117.0 (0.911 -> 0.950), 5x5 / 2 tiles at 549 MB 73.1 -> 68.9 (0.938 -> 0.995), 5x5 / 6 tiles 81.0 -> 77.4, 3x3
+// 73.3 -> 71.0; 6x6 63.3 -> 62.2, 7x7 and 8x8 within 1.5 % and cfg2's two-stream launch 118.5 -> 116.7: all left with one-wave blocks
+constexpr int kSmallDenseMaxS = 5, kSmallDenseWaves = 4, kSmallDenseExtraBlocks = 2;
+constexpr uint64_t kSmallDenseMaxBytes = 1024 * MiB;
+constexpr uint32_t kPieceSmallDenseBlocks = 64;
 constexpr uint64_t kLinesChunkRuleMaxBytes = 640 * MiB;  // four lanes per board: the 14 KB chunk rule up to this many bytes per launch
 constexpr int kLinesDenseLanes = 16, kLinesDenseWaves = 4, kLinesDenseRows = 40, kLinesDenseExtraBlocks = 2;
 constexpr uint64_t kLinesDenseExtraMaxBytes = 1024 * MiB;
@@ -2885,11 +2893,24 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     Residency res = ooc_residency(a.nt != 0, false, tfix == 0, (uint64_t)a.bpw * out_per_board, T);
     if (res.blocks_per_cu > 0 && (uint64_t)d->n_boards * (uint64_t)(T + Tt + 4 * ((C + 31) / 32) + 7) > policy::kSmallStateSpillBytes)
       res.blocks_per_cu += policy::kSmallStateSpillExtraBlocks;  // the state comes from HBM too: more waves in flight to wait for it
+    // Boards up to 5x5 in the register forms, one float32 stream of up to 1 GiB: FOUR waves per block (policy::kSmallDense*) - the
+    // waves of a block share the CU's L1 for the lines of the state rows, as with the 16-lane form of k_lines.
+    bool dense_blocks = false;
+    if (res.blocks_per_cu > 0 && res.waves_per_block == 1) {
+      int w = (int)g_small_waves.load(std::memory_order_relaxed);
+      const bool policy_says = tfix > 0 && S <= policy::kSmallDenseMaxS && a.obs && !a.onehot && out_per_board * (uint64_t)d->n_boards <= policy::kSmallDenseMaxBytes;
+      if (w == 0 && policy_says) w = policy::kSmallDenseWaves, dense_blocks = true;
+      if (w == 2 || w == 4) {
+        res.waves_per_block = w;
+        res.blocks_per_cu = (res.blocks_per_cu + w - 1) / w + (dense_blocks ? policy::kSmallDenseExtraBlocks : 0);
+      }
+    }
     if (a.emit_edges == 0xffu) {
       const uint64_t chunk = (uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch);
       const uint64_t sites = ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw * ((a.obs && a.onehot) ? 2u : 1u);
       a.emit_edges = (T + Tt + 4 * ((C + 31) / 32) + 7 >= policy::kEdgeCapStateBytes) ? edge_policy_capped(chunk, sites, true) : edge_policy(chunk);
     }
+    if (a.xcd_piece == 0xffffffffu && dense_blocks) a.xcd_piece = policy::kPieceSmallDenseBlocks;
     if (a.xcd_piece == 0xffffffffu)  // (streams beyond ~1.2 GiB in chunks of 16 KB and more - 7x7 / 8x8 half waves: eighths, see small_boards_per_wave)
       a.xcd_piece = ((uint64_t)a.bpw * out_per_board >= policy::kEighthsChunk && out_per_board * (uint64_t)d->n_boards > kHugeStreamBytes) ? 0u : piece_policy(false, (uint64_t)a.bpw * out_per_board);
     a.cached_every = a.nt ? cached_every_policy(S, out_per_board * (uint64_t)d->n_boards, a.onehot != nullptr) : 0u;
@@ -3383,7 +3404,8 @@ int64_t ts_tuning(int32_t key, int64_t value) {
                                : key == TS_TUNE_SMALL_BPW ? &g_small_bpw
                                : key == TS_TUNE_CACHED_EVERY ? &g_cached_every
                                : key == TS_TUNE_STATE_ONLY ? &g_state_only
-                               : key == TS_TUNE_LINES_WAVES ? &g_lines_waves : nullptr;
+                               : key == TS_TUNE_LINES_WAVES ? &g_lines_waves
+                               : key == TS_TUNE_SMALL_WAVES ? &g_small_waves : nullptr;
   if (!knob) return -1;
   if (key == TS_TUNE_MT_WINDOW && value > kMtLongWindow) value = kMtLongWindow;  // output 623 wraps around to twisted word 0
   return value >= 0 ? knob->exchange(value) : knob->load();
