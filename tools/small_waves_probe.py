@@ -35,6 +35,8 @@ def rate(env, act, steps=25):
 SHAPES = [(5, 2, 3, 1 << 20, True), (4, 2, 2, 1 << 22, False), (5, 2, 3, 1703936, False), (6, 3, 4, 1 << 20, False), (7, 5, 6, 850176, False), (8, 4, 8, 651008, False),
           (3, 1, 0, 4 << 20, False), (5, 6, 3, 1703936, False), (9, 4, 9, 514304, False), (10, 5, 10, 416512, False), (12, 8, 16, 289280, False), (24, 30, 60, 72192, False),
           (20, 10, 40, 103936, False), (28, 8, 60, 53248, False)]
+if len(sys.argv) > 1:  # S,T,K,N[,onehot] ...
+    SHAPES = [tuple(int(x) for x in a.split(",")[:4]) + (a.count(",") > 3,) for a in sys.argv[1:]]
 for S, T, K, N, oh in SHAPES:
     env = VecTilerSliderEnv.random(N, size=S, num_tiles=T, num_obstacles=K, seed=3, multi_color=True, max_steps=2**30, auto_reset=True, obs_candidates=0,
                                    with_onehot=oh, with_reward=oh)
