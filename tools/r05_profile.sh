@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-5 profiles (GPU box): the default bench run, then rocprofv3 --kernel-trace --stats per BASELINE config with the class
 # defaults (same command as the bench line), the entry-point kernel trace at cfg4 (k_state) and cfg1, and the one-rank RCCL
-# rehearsal of the hand-off.  PMC traffic passes: unchanged kernels, profiles/traffic_pmc.json of round 4 stands.
+# rehearsal of the hand-off.  PMC traffic passes: tools/r05_pmc_traffic.sh.
 set -o pipefail
 OUT=gpurun_out/r05_prof
 mkdir -p $OUT
