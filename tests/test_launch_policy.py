@@ -117,6 +117,17 @@ def test_size_cliffs(shape):
         assert got == want, (shape, limit, delta, got)
 
 
+def test_edge_stores_into_an_observation_ring():
+    """ts_dims.ring_bytes: the write-back edge lines of all k buffers share the cache - both edges while k x 2 KiB x chunks <= 200 MiB,
+    then one, then none (profiles/r05_ring_policy_probe.log); a single buffer keeps its own rule."""
+    def edges(n, S, T, k):
+        return describe(dims(n, S, T, ring=k * n * 12 * S * S))["emit_edges"]
+    assert [edges(1 << 18, 15, 32, k) for k in (1, 2, 3, 4)] == [3, 2, 2, 0]          # cfg4: 128 MiB of edge lines per buffer with both
+    assert [edges(1 << 22, 4, 2, k) for k in (1, 2)] == [3, 1]                          # 4M 4x4 boards: both always into one buffer, the first into two
+    assert [edges(162560, 16, 16, k) for k in (1, 2)] == [3, 3]                          # 16x16 at 514 MB: 159 MiB for a ring of two
+    assert [edges(1 << 20, 4, 2, k) for k in (1, 2)] == [0, 3]                          # cfg1: cache-resident alone (no edges), beyond the cache as a ring
+
+
 def test_sixteen_lane_boards_run_four_wave_blocks():
     """k_lines beyond the cache: four waves per block with 16 lanes per board (profiles/r05_lines_waves_per_block_probe.log); one-wave
     blocks with 8 and 32 lanes, for two-stream launches, and when ts_tuning(TS_TUNE_LINES_WAVES) says so."""

@@ -2544,6 +2544,7 @@ constexpr uint64_t kEdgeMinChunk = 8 * KiB;
 // ... and their absolute cap per launch, 1 KiB per edge instruction and chunk (r04_large_batch_edges*.log, r04_knee_probe.log: beyond
 // ~150 MB of cached edge bytes the kernels that read much state per board lose half their rate - cfg4's shape at 1.4 GB 401.8 us
 // with both edges, 214.4 with the last only, 212.0 with none); beyond 1 GiB per launch a little less is tolerated (24x24 at 2.1 GB)
+constexpr uint64_t kEdgeCapRing = 200 * MiB;  // all buffers of an observation ring together (edge_policy_capped)
 constexpr uint64_t kEdgeCapBytes = 152 * MiB, kEdgeCapBytesBeyond = 128 * MiB, kEdgeCapOneBeyond = 112 * MiB, kEdgeCapSwitch = 1024 * MiB, kEdgeBytesPerSite = 1 * KiB;
 constexpr int kEdgeCapStateBytes = 20;  // k_small forms with fewer bytes of state per board keep both edges at any size (4x4 / 5x5 with two
                                         // tiles at 1 GB: both 149 / 146 us, one 154 - 166, none 173 / 176; r04_large_batch_edges_small_boards*.log)
@@ -2647,8 +2648,18 @@ uint32_t edge_policy(uint64_t obs_chunk) { return obs_chunk >= policy::kEdgeMinC
 // the any-tile-count path at 6x6 / 12 tiles 272 -> 234 at 1.4 GB: r04_large_batch_edges_small_boards*.log) - the cached share
 // competes with the state for the caches.  The cap is what one 28x28 board per wave at 700 MB needs (152 MB, 0.97 with both).
 // Beyond 1 GiB per launch a little less is tolerated (24x24 at 2.1 GB with one edge, 148 MiB: 425 us; with none: 344).
-uint32_t edge_policy_capped(uint64_t obs_chunk, uint64_t edge_instruction_sites, bool keep_first) {
+// Into a RING of k >= 2 observation buffers (ts_dims.ring_bytes) the edge lines of all k buffers have to stay in the cache side by
+// side: both edges while k x 2 KiB x chunks <= 200 MiB, then one, then none (profiles/r05_ring_policy_probe.log, rings of two, us per
+// step with none / first / last / both): 16x16 at 514 MB (159 MiB of edge lines) 82.8 / 73.6 / 73.7 / 64.4; cfg4 (256 MiB)
+// 110.5 / 110.0 / 105.0 / 165.1 - 104.0 into a single buffer; 4x4 at 4M boards (256 MiB) 137.5 / 125.8 / 126.2 / 139.9.  The cached
+// waves keep their single-buffer rule (6x6: 63.0 us against 68.2 without them).
+uint32_t edge_policy_capped(uint64_t obs_chunk, uint64_t edge_instruction_sites, bool keep_first, uint32_t ring_buffers = 1) {
   uint32_t e = edge_policy(obs_chunk);
+  if (ring_buffers >= 2) {
+    const uint64_t one = policy::kEdgeBytesPerSite * edge_instruction_sites * ring_buffers;
+    if (e == 3u && 2u * one > policy::kEdgeCapRing) e = one <= policy::kEdgeCapRing ? (keep_first ? 1u : 2u) : 0u;
+    return e;
+  }
   const uint64_t kCap = obs_chunk * edge_instruction_sites > policy::kEdgeCapSwitch ? policy::kEdgeCapBytesBeyond : policy::kEdgeCapBytes;
   if (e == 3u && 2u * policy::kEdgeBytesPerSite * edge_instruction_sites > kCap) e = keep_first ? 1u : 2u;  // one edge instruction only
   // ... and a single edge beyond 1 GiB per launch pays up to ~111 MiB of it (16x16 / 8x8 with 20 tiles at 1.4 GB: 219 / 232 us against
@@ -2804,6 +2815,9 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     plan.resident_bytes = plan.output_bytes && (uint64_t)d->ring_bytes > plan.output_bytes ? (uint64_t)d->ring_bytes : plan.output_bytes;
     a.nt = plan.resident_bytes > (uint64_t)g_nt_threshold_bytes.load(std::memory_order_relaxed) ? 1u : 0u;
   }
+  // Buffers of the ring the launch writes into (1 = no ring): the write-back edge stores of k alternating buffers keep k times their
+  // bytes alive in the cache (edge_policy_capped)
+  const uint32_t ring_k = (uint32_t)(plan.output_bytes ? (plan.resident_bytes + plan.output_bytes - 1) / plan.output_bytes : 1u);
   plan.S = S;
   if (a.nt) {
     const int64_t piece = g_xcd_piece.load(std::memory_order_relaxed);
@@ -2865,7 +2879,7 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
         apply_launch_hint(res, d->launch_hint);
         if (a.emit_edges == 0xffu)  // chunks (and 8 KiB pieces of the plane stream) that carry edge instructions
           a.emit_edges = edge_policy_capped((uint64_t)bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch),
-                                                ((uint64_t)d->n_boards + bpw - 1) / bpw + (a.onehot ? (uint64_t)d->n_boards * C * a.onehot_ch / 8192u : 0u), false);
+                                                ((uint64_t)d->n_boards + bpw - 1) / bpw + (a.onehot ? (uint64_t)d->n_boards * C * a.onehot_ch / 8192u : 0u), false, ring_k);
         if (a.xcd_piece == 0xffffffffu) a.xcd_piece = piece_policy(true, 0);
         a.cached_every = a.nt ? cached_every_policy(0, 0, true) : 0u;  // k_deal: only when forced (8x8 with 12 tiles -1 %, with 20 tiles 0)
         int waves = res.waves_per_block > 0 ? res.waves_per_block : TS_WAVES_PER_BLOCK;
@@ -2908,7 +2922,7 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     if (a.emit_edges == 0xffu) {
       const uint64_t chunk = (uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch);
       const uint64_t sites = ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw * ((a.obs && a.onehot) ? 2u : 1u);
-      a.emit_edges = (T + Tt + 4 * ((C + 31) / 32) + 7 >= policy::kEdgeCapStateBytes) ? edge_policy_capped(chunk, sites, true) : edge_policy(chunk);
+      a.emit_edges = (T + Tt + 4 * ((C + 31) / 32) + 7 >= policy::kEdgeCapStateBytes || ring_k >= 2) ? edge_policy_capped(chunk, sites, true, ring_k) : edge_policy(chunk);
     }
     if (a.xcd_piece == 0xffffffffu && dense_blocks) a.xcd_piece = policy::kPieceSmallDenseBlocks;
     if (a.xcd_piece == 0xffffffffu)  // (streams beyond ~1.2 GiB in chunks of 16 KB and more - 7x7 / 8x8 half waves: eighths, see small_boards_per_wave)
@@ -3024,7 +3038,7 @@ int32_t plan_launch(const ts_dims *d, const ts_state *st, KArgs a, LaunchPlan &p
     apply_launch_hint(res, d->launch_hint);
     if (a.emit_edges == 0xffu)
       a.emit_edges = edge_policy_capped((uint64_t)a.bpw * (a.obs ? 12ull * C : 4ull * C * a.onehot_ch),
-                                            ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw + (a.onehot ? (uint64_t)d->n_boards * C * a.onehot_ch / 8192u : 0u), false);
+                                            ((uint64_t)d->n_boards + a.bpw - 1) / a.bpw + (a.onehot ? (uint64_t)d->n_boards * C * a.onehot_ch / 8192u : 0u), false, ring_k);
     if (a.xcd_piece == 0xffffffffu) a.xcd_piece = dense_blocks ? policy::kPieceDenseBlocks : piece_policy(true, 0);
     a.cached_every = a.nt ? cached_every_policy(S, (uint64_t)d->n_boards * ((a.obs ? 12ull * C : 0ull) + (a.onehot ? 4ull * C * a.onehot_ch : 0ull) + (a.obs_u8 ? 3ull * C : 0ull)),
                                                         a.onehot != nullptr) : 0u;
