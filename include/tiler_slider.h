@@ -125,7 +125,8 @@ typedef struct ts_dims {
                         * buffers: k x the observation bytes, plus the one-hot planes).  A launch is classified as cache-resident
                         * or beyond the 256 MiB Infinity Cache by max(its own output bytes, ring_bytes): two alternating 201-MB
                         * buffers are a 402-MB working set, and agent-scope stores into it are the wrong policy
-                        * (profiles/r05_ring_probe.log).  Speed only. */
+                        * (profiles/r05_ring_probe.log); and the write-back edge stores of all the ring's buffers share one cap
+                        * (cfg4 into a ring of two: 170.6 -> 105.5 us, profiles/r05_ring_policy_probe.log).  Speed only. */
 } ts_dims;
 
 typedef struct ts_state {
