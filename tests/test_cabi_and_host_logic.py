@@ -311,26 +311,27 @@ def test_no_64bit_read_of_the_last_allocated_vgpr():
 
 def test_vgpr_allocation_padding_rule():
     """Descriptor AND metadata are edited; 48 (fills its allocation, below 64) is padded, 49 / 33 are not; from 64 on a
-    kernel is padded only when the scanner named it (a granule more costs a wave per SIMD there)."""
+    kernel is padded when the scanner named it or when the next granule holds as many waves per SIMD (104 -> 112)."""
     asm = "\n".join([
         "\t.amdhsa_kernel k_full", "\t\t.amdhsa_next_free_vgpr 48", "\t\t.amdhsa_accum_offset 48", "\t.end_amdhsa_kernel",
         "\t.amdhsa_kernel k_slack", "\t\t.amdhsa_next_free_vgpr 49", "\t.end_amdhsa_kernel",
         "\t.amdhsa_kernel k_big_clean", "\t\t.amdhsa_next_free_vgpr 64", "\t.end_amdhsa_kernel",
         "\t.amdhsa_kernel k_big_hit", "\t\t.amdhsa_next_free_vgpr 96", "\t.end_amdhsa_kernel",
-        "amdhsa.kernels:", "  - .agpr_count:     0", "    .name:           k_full", "    .vgpr_count:     48",
+        "\t.amdhsa_kernel k_big_free", "\t\t.amdhsa_next_free_vgpr 104", "\t.end_amdhsa_kernel",
+        "amdhsa.kernels:", "  - .agpr_count:     0", "    .name:           k_big_free", "    .vgpr_count:     104", "  - .agpr_count:     0", "    .name:           k_full", "    .vgpr_count:     48",
         "  - .agpr_count:     0", "    .name:           k_slack", "    .vgpr_count:     49",
         "  - .agpr_count:     0", "    .name:           k_big_clean", "    .vgpr_count:     64",
         "  - .agpr_count:     0", "    .name:           k_big_hit", "    .vgpr_count:     96"])
     from tiler_slider_amd import _cabi, _vgpr_guard
     out, padded = _vgpr_guard.pad_vgpr_allocations(asm, hits={"k_big_hit"})
-    assert padded == {"k_full": (48, "free"), "k_big_hit": (96, "hit")}
-    for name, n in (("k_full", 49), ("k_slack", 49), ("k_big_clean", 64), ("k_big_hit", 97)):
+    assert padded == {"k_full": (48, "free"), "k_big_hit": (96, "hit"), "k_big_free": (104, "free")}   # 104 -> 112 registers: four waves either way
+    for name, n in (("k_full", 49), ("k_slack", 49), ("k_big_clean", 64), ("k_big_hit", 97), ("k_big_free", 105)):
         assert re.search(rf"\.amdhsa_kernel {name}\n\s+\.amdhsa_next_free_vgpr {n}\b", out), name
         assert re.search(rf"\.name:\s+{name}\n\s+\.vgpr_count:\s+{n}\b", out), name
     assert ".amdhsa_accum_offset 48" in out
     # blanket rule (round 3) through the _cabi wrapper: every full allocation
     out, n = _cabi.pad_vgpr_allocations(asm)
-    assert n == 3 and ".amdhsa_next_free_vgpr 65" in out
+    assert n == 4 and ".amdhsa_next_free_vgpr 65" in out
     assert [_vgpr_guard.waves_per_simd(v) for v in (32, 64, 65, 96, 97, 128, 129)] == [8, 8, 7, 5, 4, 4, 3]
 
 

@@ -169,7 +169,7 @@ def compile_guarded(src, out_lib, defines=(), work=None, verbose=False, keep_asm
             os.remove(base + ext)
     if verbose:
         print(f"VGPR guard: {report['padded']} of {report['allocation_full']} full allocations padded "
-              f"({report['padded_free_below_64']} below 64 registers, {len(hits)} on a scanner hit); "
+              f"({report['padded_free_below_64']} at no cost in waves per SIMD, {len(hits)} on a scanner hit); "
               f"{sum(1 for e in report['at_or_above_64'] if not e['padded'])} at or above 64 left alone (no 64-bit read of the last register)")
     return report
 

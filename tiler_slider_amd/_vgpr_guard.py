@@ -113,8 +113,9 @@ def scan(lib):
 
 def pad_vgpr_allocations(asm, hits=None):
     """Device assembly -> (patched assembly, {kernel: (vgprs before, reason)}).  A kernel whose VGPR count fills its
-    allocation exactly gets one register more in its descriptor and metadata when the count is below FREE_BELOW (no
-    occupancy cost: "free"), or when `hits` (kernel names with a scanner finding in the unpadded object) names it ("hit").
+    allocation exactly gets one register more in its descriptor and metadata when that costs no wave per SIMD - below
+    FREE_BELOW, and at 88 / 104 / 112 / 120 registers, where the next granule holds as many waves ("free") -, or when `hits`
+    (kernel names with a scanner finding in the unpadded object) names it ("hit").
     hits=None pads every such kernel (round 3's blanket rule)."""
     padded, out, in_meta, name, kernel = {}, [], False, None, None
     for line in asm.split("\n"):
@@ -124,7 +125,8 @@ def pad_vgpr_allocations(asm, hits=None):
         elif t.startswith(".amdhsa_next_free_vgpr ") and kernel:
             n = int(t.split()[1])
             if n > 0 and n % GRANULE == 0:
-                reason = "free" if n < FREE_BELOW else "hit" if (hits is None or kernel in hits) else None
+                free = n < FREE_BELOW or waves_per_simd(n + 1) == waves_per_simd(n)  # (88, 104, 112, 120: the next granule holds as many waves)
+                reason = "free" if free else "hit" if (hits is None or kernel in hits) else None
                 if reason:
                     if n + 1 > SIMD_VGPRS:
                         raise ValueError(f"{kernel}: cannot pad {n} VGPRs")
