@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, call 34 (GPU box; needs the experiment commit before "removed" in git log - the issue thread is not in the tree): the gatherer's issue thread: RCCL world-1 tests, host profile of the loops, the one-rank rehearsal of bench.py.
+# Round 5, call 34 (GPU box): the hand-off with its collectives issued by a helper thread (an experiment that was measured and dropped before it was committed: this script is kept as the record of what ran; bench.py no longer prints the issue-thread figures it reads).
 set -o pipefail
 OUT=gpurun_out/r05_call34
 mkdir -p $OUT
