@@ -150,6 +150,8 @@ def compile_guarded(src, out_lib, defines=(), work=None, verbose=False, keep_asm
                             "waves_per_simd_if_padded": guard.waves_per_simd(counts0[k][0] + 1)}
                            for k in full if counts0[k][0] >= guard.FREE_BELOW],
         "hits_in_final_object": {"class_a": len(a1), "class_b": len(b1)},
+        # kernels that use accumulation registers are not scanned (their last VGPR is an AGPR): reported, so that one appearing is seen
+        "kernels_with_agprs": sorted(k for k, (n, ag) in counts0.items() if ag > 0),
     }
     json.dump(report, open(os.path.join(work, "vgpr_guard.json"), "w"), indent=1)
     if a1 or b1:
